@@ -1,0 +1,165 @@
+"""ctypes binding of oracle/libaslam_oracle.so (the C++ restatement).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libaslam_oracle.so")
+
+EKF, UKF = 0, 1
+_KIND = {"ekf": EKF, "ukf": UKF}
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, n) for n in ("aslam_oracle.cpp", "aslam_oracle.h", "Makefile")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libaslam_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        c_dp = ctypes.POINTER(ctypes.c_double)
+        c_fp = ctypes.POINTER(ctypes.c_float)
+        vp = ctypes.c_void_p
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_sensor.argtypes = [vp, ctypes.c_int, c_dp, c_dp]
+        L.orc_odom.restype = ctypes.c_int
+        L.orc_odom.argtypes = [vp] + [ctypes.c_double] * 8 + [ctypes.c_float]
+        L.orc_slam.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+        L.orc_dim.restype = ctypes.c_int
+        L.orc_dim.argtypes = [vp]
+        L.orc_get.argtypes = [vp, c_dp, c_dp, c_dp]
+        L.orc_get_A.argtypes = [vp, c_dp, c_dp]
+        L.orc_set.argtypes = [vp, ctypes.c_int, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double]
+        L.orc_wait_size.restype = ctypes.c_int
+        L.orc_wait_size.argtypes = [vp]
+        L.orc_get_wait.argtypes = [vp, c_fp, c_fp, ctypes.POINTER(ctypes.c_uint32)]
+        L.orc_sensor_size.restype = ctypes.c_int
+        L.orc_sensor_size.argtypes = [vp]
+        L.orc_get_sensor.argtypes = [vp, c_fp, c_fp]
+        L.orc_get_weights.argtypes = [vp, c_dp, c_fp]
+        L.orc_replay.restype = ctypes.c_int64
+        L.orc_replay.argtypes = [vp, ctypes.c_int64, c_dp, c_fp, ctypes.POINTER(ctypes.c_uint8),
+                                 ctypes.POINTER(ctypes.c_int32), c_dp, ctypes.c_int, c_dp,
+                                 ctypes.POINTER(ctypes.c_int32)]
+        L.orc_normalize_angle.restype = ctypes.c_float
+        L.orc_normalize_angle.argtypes = [ctypes.c_float]
+        L.orc_quat2euler.restype = ctypes.c_float
+        L.orc_quat2euler.argtypes = [ctypes.c_float] * 4
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+class CFilter:
+    """EKFSlam / UKFSlam of the reference, ROS-free (C++ restatement)."""
+
+    def __init__(self, kind, max_landmark_count=30):
+        self.kind = kind
+        self._h = lib().orc_create(_KIND[kind], int(max_landmark_count))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def sensor_msg(self, xs, ys):
+        xs = np.ascontiguousarray(xs, np.float64)
+        ys = np.ascontiguousarray(ys, np.float64)
+        lib().orc_sensor(self._h, len(xs), _p(xs, ctypes.c_double), _p(ys, ctypes.c_double))
+
+    def odom_msg(self, px, py, qw, qx, qy, qz, vx, wz, dt):
+        return lib().orc_odom(self._h, px, py, qw, qx, qy, qz, vx, wz, float(np.float32(dt)))
+
+    def slam(self, vx, az, dt):
+        lib().orc_slam(self._h, float(np.float32(vx)), float(np.float32(az)), float(np.float32(dt)))
+
+    @property
+    def N(self):
+        return lib().orc_dim(self._h)
+
+    def state(self):
+        n = self.N
+        X, Z, P = np.empty(n), np.empty(n), np.empty((n, n))
+        lib().orc_get(self._h, _p(X, ctypes.c_double), _p(Z, ctypes.c_double), _p(P, ctypes.c_double))
+        return X, Z, P
+
+    @property
+    def X(self):
+        return self.state()[0]
+
+    @property
+    def Z(self):
+        return self.state()[1]
+
+    @property
+    def P(self):
+        return self.state()[2]
+
+    def A(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        lib().orc_get_A(self._h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def set_state(self, N, X, Z, P, a00=1.0, a10=0.0):
+        X = np.ascontiguousarray(X, np.float64)
+        Z = np.ascontiguousarray(Z, np.float64)
+        P = np.ascontiguousarray(P, np.float64)
+        lib().orc_set(self._h, int(N), _p(X, ctypes.c_double), _p(Z, ctypes.c_double), _p(P, ctypes.c_double),
+                      float(a00), float(a10))
+
+    def wait_list(self):
+        k = lib().orc_wait_size(self._h)
+        r, b, c = np.empty(k, np.float32), np.empty(k, np.float32), np.empty(k, np.uint32)
+        if k:
+            lib().orc_get_wait(self._h, _p(r, ctypes.c_float), _p(b, ctypes.c_float), _p(c, ctypes.c_uint32))
+        return r, b, c
+
+    def sensor_list(self):
+        k = lib().orc_sensor_size(self._h)
+        r, b = np.empty(k, np.float32), np.empty(k, np.float32)
+        if k:
+            lib().orc_get_sensor(self._h, _p(r, ctypes.c_float), _p(b, ctypes.c_float))
+        return r, b
+
+    def weights(self):
+        w = np.empty(2 * self.N + 5)
+        lam = ctypes.c_float()
+        lib().orc_get_weights(self._h, _p(w, ctypes.c_double), ctypes.byref(lam))
+        return w, np.float32(lam.value)
+
+    def replay(self, traj, T=None):
+        """Run one trajectory (awesomeslam_amd.trace.Trajectory); returns poses[T,3], dims[T]."""
+        T = traj.T if T is None else int(T)
+        odom = np.ascontiguousarray(traj.odom[:T], np.float64)
+        dt = np.ascontiguousarray(traj.dt[:T], np.float32)
+        on = np.ascontiguousarray(traj.obs_new[:T], np.uint8)
+        no = np.ascontiguousarray(traj.n_obs[:T], np.int32)
+        obs = np.ascontiguousarray(traj.obs[:T], np.float64)
+        poses = np.zeros((T, 3))
+        dims = np.zeros(T, np.int32)
+        lib().orc_replay(self._h, T, _p(odom, ctypes.c_double), _p(dt, ctypes.c_float), _p(on, ctypes.c_uint8),
+                         _p(no, ctypes.c_int32), _p(obs, ctypes.c_double), traj.max_obs,
+                         _p(poses, ctypes.c_double), _p(dims, ctypes.c_int32))
+        return poses, dims
+
+
+def normalize_angle(theta):
+    return np.float32(lib().orc_normalize_angle(float(np.float32(theta))))
+
+
+def quat2euler(w, x, y, z):
+    return np.float32(lib().orc_quat2euler(*[float(np.float32(v)) for v in (w, x, y, z)]))
