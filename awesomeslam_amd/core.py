@@ -1,0 +1,343 @@
+"""ctypes binding of libaslam_core.so / libaslam_node.so (include/aslam_core.h, csrc/host/aslam_node.h).
+
+This is plumbing: every number comes out of the HIP kernels.  There is no CPU fallback -- if the shared
+library is missing, or no HIP device is present, the calls raise (AslamError / OSError).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_CORE = os.path.join(_CSRC, "libaslam_core.so")
+_NODE = os.path.join(_CSRC, "libaslam_node.so")
+
+EKF, UKF = 0, 1
+F64, F32 = 0, 1
+FILTERS = {"ekf": EKF, "ukf": UKF}
+
+ST_GROWTH_REFUSED, ST_WAIT_OVERFLOW, ST_NOT_PD, ST_OBS_OVERFLOW = 1, 2, 4, 8
+
+# every symbol include/aslam_core.h declares (tests check the library exports them all)
+CORE_SYMBOLS = (
+    "aslam_create", "aslam_destroy", "aslam_reset", "aslam_last_error", "aslam_abi_version", "aslam_set_state",
+    "aslam_grow", "aslam_ekf_step", "aslam_ukf_step", "aslam_set_trace", "aslam_replay", "aslam_get_dim",
+    "aslam_get_state", "aslam_get_A", "aslam_get_landmarks", "aslam_get_wait", "aslam_get_status",
+    "aslam_get_layout", "aslam_kernel_info",
+)
+NODE_SYMBOLS = (
+    "aslam_node_create", "aslam_node_destroy", "aslam_node_error", "aslam_node_sensor", "aslam_node_odom",
+    "aslam_node_odom_now", "aslam_node_dim", "aslam_node_get", "aslam_node_wait", "aslam_node_core",
+    "aslam_host_narrow_odom",
+)
+
+
+class AslamError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in
+                ("filter", "dtype", "max_landmark_count", "batch", "max_obs", "max_wait", "device", "reserved")]
+
+
+class TraceView(ctypes.Structure):
+    _fields_ = [("T", ctypes.c_int64), ("max_obs", ctypes.c_int32), ("is_device", ctypes.c_int32),
+                ("pose", ctypes.c_void_p), ("yaw", ctypes.c_void_p), ("twist", ctypes.c_void_p),
+                ("dt", ctypes.c_void_p), ("obs_new", ctypes.c_void_p), ("n_obs", ctypes.c_void_p),
+                ("obs", ctypes.c_void_p)]
+
+
+def build(force=False, ukf=True):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(_CSRC, "host", f) for f in os.listdir(os.path.join(_CSRC, "host"))]
+    srcs += [os.path.join(_CSRC, "Makefile"), os.path.join(_CSRC, "..", "..", "include", "aslam_core.h")]
+    stale = force or not (os.path.exists(_CORE) and os.path.exists(_NODE)) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(_CORE), os.path.getmtime(_NODE)) for s in srcs)
+    if stale:
+        have_ukf = ukf and os.path.exists(os.path.join(_CSRC, "ukf_small.h"))
+        subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "all"])
+    return _CORE, _NODE
+
+
+_core = None
+_node = None
+
+
+def core_lib():
+    global _core
+    if _core is None:
+        if not os.path.exists(_CORE):
+            raise OSError(f"{_CORE} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the filter core)")
+        L = ctypes.CDLL(_CORE)
+        vp, ci, cf, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
+        pd, pf, pi, pu = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_float, ctypes.c_int, ctypes.c_uint32))
+        L.aslam_last_error.restype = ctypes.c_char_p
+        L.aslam_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+        L.aslam_destroy.argtypes = [vp]
+        L.aslam_reset.argtypes = [vp]
+        L.aslam_set_state.argtypes = [vp, ci, ci, pd, pd, pd]
+        L.aslam_grow.argtypes = [vp, ci, ci, pd, pd]
+        L.aslam_ekf_step.argtypes = [vp, ci, cf, cf, cf, pd, cd, cd, pd, vp]
+        L.aslam_ukf_step.argtypes = [vp, ci, cf, cf, cf, pd, pd, vp]
+        L.aslam_set_trace.argtypes = [vp, ctypes.POINTER(TraceView)]
+        L.aslam_replay.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
+        L.aslam_get_dim.argtypes = [vp, ci, pi]
+        L.aslam_get_state.argtypes = [vp, ci, pd, pd, pd]
+        L.aslam_get_A.argtypes = [vp, ci, pd, pd]
+        L.aslam_get_landmarks.argtypes = [vp, ci, pd, pd, pi]
+        L.aslam_get_wait.argtypes = [vp, ci, pf, pf, pu, ci, pi]
+        L.aslam_get_status.argtypes = [vp, ci, pu]
+        L.aslam_get_layout.argtypes = [vp, pi, ctypes.POINTER(ctypes.c_int64)]
+        L.aslam_kernel_info.argtypes = [vp, ctypes.c_char_p, ci, pi, pi, pi]
+        _core = L
+    return _core
+
+
+def node_lib():
+    global _node
+    if _node is None:
+        if not os.path.exists(_NODE):
+            raise OSError(f"{_NODE} is missing: run __graft_entry__.build()")
+        core_lib()
+        L = ctypes.CDLL(_NODE)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        pd, pf, pu = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_float, ctypes.c_uint32))
+        L.aslam_node_create.restype = vp
+        L.aslam_node_create.argtypes = [ci, ci, ci]
+        L.aslam_node_destroy.argtypes = [vp]
+        L.aslam_node_error.restype = ctypes.c_char_p
+        L.aslam_node_sensor.argtypes = [vp, ci, pd, pd]
+        L.aslam_node_odom.argtypes = [vp, pd, ctypes.c_float]
+        L.aslam_node_odom_now.argtypes = [vp, pd, ctypes.c_double]
+        L.aslam_node_dim.argtypes = [vp]
+        L.aslam_node_get.argtypes = [vp, pd, pd, pd, pd]
+        L.aslam_node_wait.argtypes = [vp, pf, pf, pu, ci]
+        L.aslam_node_core.restype = vp
+        L.aslam_node_core.argtypes = [vp]
+        L.aslam_host_narrow_odom.argtypes = [ctypes.c_int64, pd, pd, pf, pd]
+        _node = L
+    return _node
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _chk(rc):
+    if rc != 0:
+        raise AslamError(f"aslam_core error {rc}: {core_lib().aslam_last_error().decode()}")
+
+
+def narrow_odom(odom):
+    """Message-level odometry [..., 8] -> (pose [..., 2] f64, yaw [...] f32, twist [..., 2] f64), done by the
+    C++ host mirror so that quat2euler is the host libm's atan2f (tools.h:62-66)."""
+    odom = np.ascontiguousarray(odom, np.float64)
+    lead = odom.shape[:-1]
+    cnt = int(np.prod(lead))
+    pose = np.empty(lead + (2,), np.float64)
+    yaw = np.empty(lead, np.float32)
+    twist = np.empty(lead + (2,), np.float64)
+    node_lib().aslam_host_narrow_odom(cnt, _ptr(odom, ctypes.c_double), _ptr(pose, ctypes.c_double),
+                                      _ptr(yaw, ctypes.c_float), _ptr(twist, ctypes.c_double))
+    return pose, yaw, twist
+
+
+class Core:
+    """One libaslam_core context: `batch` independent filters resident on one GPU."""
+
+    def __init__(self, filter="ekf", max_landmark_count=30, batch=1, max_obs=16, max_wait=128, device=0, dtype=F64):
+        self.filter = filter
+        self.batch = int(batch)
+        self.max_obs = int(max_obs)
+        cfg = Config(FILTERS[filter], dtype, int(max_landmark_count), int(batch), int(max_obs), int(max_wait),
+                     int(device), 0)
+        h = ctypes.c_void_p()
+        _chk(core_lib().aslam_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._trace_keep = None
+        self.T = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            core_lib().aslam_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _chk(core_lib().aslam_reset(self._h))
+
+    # ---- per-callback seam
+    def set_state(self, traj, n, X=None, Z=None, P=None):
+        X, Z, P = (None if a is None else np.ascontiguousarray(a, np.float64) for a in (X, Z, P))
+        _chk(core_lib().aslam_set_state(self._h, traj, int(n), _ptr(X, ctypes.c_double), _ptr(Z, ctypes.c_double),
+                                        _ptr(P, ctypes.c_double)))
+
+    def grow(self, traj, n_new, x_seed, z_seed):
+        x_seed = np.ascontiguousarray(x_seed, np.float64)
+        z_seed = np.ascontiguousarray(z_seed, np.float64)
+        _chk(core_lib().aslam_grow(self._h, traj, int(n_new), _ptr(x_seed, ctypes.c_double), _ptr(z_seed, ctypes.c_double)))
+
+    def ekf_step(self, traj, vx, az, dt, Z, a00, a10, stream=None):
+        Z = np.ascontiguousarray(Z, np.float64)
+        X = np.empty(len(Z))
+        _chk(core_lib().aslam_ekf_step(self._h, traj, float(np.float32(vx)), float(np.float32(az)), float(np.float32(dt)),
+                                       _ptr(Z, ctypes.c_double), float(a00), float(a10), _ptr(X, ctypes.c_double), stream))
+        return X
+
+    def ukf_step(self, traj, vx, az, dt, Z, stream=None):
+        Z = np.ascontiguousarray(Z, np.float64)
+        X = np.empty(len(Z))
+        _chk(core_lib().aslam_ukf_step(self._h, traj, float(np.float32(vx)), float(np.float32(az)), float(np.float32(dt)),
+                                       _ptr(Z, ctypes.c_double), _ptr(X, ctypes.c_double), stream))
+        return X
+
+    # ---- replay seam
+    def set_trace(self, trace):
+        """Bind a message-level awesomeslam_amd.trace.Trace (B == batch): narrowed on the host, copied to HBM."""
+        if trace.B != self.batch or trace.max_obs != self.max_obs:
+            raise ValueError(f"trace is B={trace.B}, max_obs={trace.max_obs}; context is B={self.batch}, max_obs={self.max_obs}")
+        pose, yaw, twist = narrow_odom(trace.odom)
+        arrs = dict(pose=pose, yaw=yaw, twist=twist, dt=np.ascontiguousarray(trace.dt, np.float32),
+                    obs_new=np.ascontiguousarray(trace.obs_new, np.uint8),
+                    n_obs=np.ascontiguousarray(trace.n_obs, np.int32), obs=np.ascontiguousarray(trace.obs, np.float32))
+        tv = TraceView(trace.T, trace.max_obs, 0, *(arrs[k].ctypes.data for k in ("pose", "yaw", "twist", "dt", "obs_new", "n_obs", "obs")))
+        _chk(core_lib().aslam_set_trace(self._h, ctypes.byref(tv)))
+        self.T = trace.T
+
+    def set_trace_device(self, T, pose, yaw, twist, dt, obs_new, n_obs, obs):
+        """Bind device-resident arrays (raw device pointers as ints, e.g. torch.Tensor.data_ptr())."""
+        tv = TraceView(int(T), self.max_obs, 1, pose, yaw, twist, dt, obs_new, n_obs, obs)
+        _chk(core_lib().aslam_set_trace(self._h, ctypes.byref(tv)))
+        self.T = int(T)
+
+    def replay(self, t0, nsteps, poses_ptr=None, dims_ptr=None, stream=None):
+        """Asynchronous.  poses_ptr / dims_ptr: raw device pointers ([batch][nsteps][3] f64, [batch][nsteps] i32)."""
+        _chk(core_lib().aslam_replay(self._h, int(t0), int(nsteps), poses_ptr, dims_ptr, stream))
+
+    # ---- read-back
+    def dim(self, traj=0):
+        n = ctypes.c_int()
+        _chk(core_lib().aslam_get_dim(self._h, traj, ctypes.byref(n)))
+        return n.value
+
+    def state(self, traj=0, with_P=True):
+        n = self.dim(traj)
+        X, Z = np.empty(n), np.empty(n)
+        P = np.empty((n, n)) if with_P else None
+        _chk(core_lib().aslam_get_state(self._h, traj, _ptr(X, ctypes.c_double), _ptr(Z, ctypes.c_double), _ptr(P, ctypes.c_double)))
+        return X, Z, P
+
+    def A(self, traj=0):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        _chk(core_lib().aslam_get_A(self._h, traj, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def landmarks(self, traj=0):
+        n = self.dim(traj)
+        L = (n - 3) // 2
+        x, y = np.empty(L), np.empty(L)
+        k = ctypes.c_int()
+        _chk(core_lib().aslam_get_landmarks(self._h, traj, _ptr(x, ctypes.c_double), _ptr(y, ctypes.c_double), ctypes.byref(k)))
+        return x[: k.value], y[: k.value]
+
+    def wait_list(self, traj=0, cap=512):
+        r, b, c = np.empty(cap, np.float32), np.empty(cap, np.float32), np.empty(cap, np.uint32)
+        k = ctypes.c_int()
+        _chk(core_lib().aslam_get_wait(self._h, traj, _ptr(r, ctypes.c_float), _ptr(b, ctypes.c_float), _ptr(c, ctypes.c_uint32), cap, ctypes.byref(k)))
+        k = min(k.value, cap)
+        return r[:k], b[:k], c[:k]
+
+    def status(self, traj=0):
+        s = ctypes.c_uint32()
+        _chk(core_lib().aslam_get_status(self._h, traj, ctypes.byref(s)))
+        return s.value
+
+    def layout(self):
+        npad, nbytes = ctypes.c_int(), ctypes.c_int64()
+        _chk(core_lib().aslam_get_layout(self._h, ctypes.byref(npad), ctypes.byref(nbytes)))
+        return npad.value, nbytes.value
+
+    def kernel_info(self):
+        name = ctypes.create_string_buffer(128)
+        g, b, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _chk(core_lib().aslam_kernel_info(self._h, name, 128, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
+        return {"name": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+class Node:
+    """aslam::EKFSlam / aslam::UKFSlam host mirror (C++), driving the per-callback seam of the core."""
+
+    def __init__(self, filter="ekf", max_landmark_count=30, device=0):
+        h = node_lib().aslam_node_create(FILTERS[filter], int(max_landmark_count), int(device))
+        if not h:
+            raise AslamError(node_lib().aslam_node_error().decode())
+        self._h = ctypes.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            node_lib().aslam_node_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def sensor_msg(self, xs, ys):
+        xs = np.ascontiguousarray(xs, np.float64)
+        ys = np.ascontiguousarray(ys, np.float64)
+        node_lib().aslam_node_sensor(self._h, len(xs), _ptr(xs, ctypes.c_double), _ptr(ys, ctypes.c_double))
+
+    def odom_msg(self, msg8, dt):
+        m = np.ascontiguousarray(msg8, np.float64)
+        rc = node_lib().aslam_node_odom(self._h, _ptr(m, ctypes.c_double), float(np.float32(dt)))
+        if rc < 0:
+            raise AslamError(node_lib().aslam_node_error().decode())
+        return rc
+
+    def odom_msg_now(self, msg8, now):
+        m = np.ascontiguousarray(msg8, np.float64)
+        rc = node_lib().aslam_node_odom_now(self._h, _ptr(m, ctypes.c_double), float(now))
+        if rc < 0:
+            raise AslamError(node_lib().aslam_node_error().decode())
+        return rc
+
+    @property
+    def N(self):
+        return node_lib().aslam_node_dim(self._h)
+
+    def state(self):
+        n = self.N
+        X, Z = np.empty(n), np.empty(n)
+        a, b = ctypes.c_double(), ctypes.c_double()
+        node_lib().aslam_node_get(self._h, _ptr(X, ctypes.c_double), _ptr(Z, ctypes.c_double), ctypes.byref(a), ctypes.byref(b))
+        return X, Z, a.value, b.value
+
+    def P(self):
+        n = self.N
+        P = np.empty((n, n))
+        core = ctypes.c_void_p(node_lib().aslam_node_core(self._h))
+        _chk(core_lib().aslam_get_state(core, 0, None, None, _ptr(P, ctypes.c_double)))
+        return P
+
+    def wait_list(self, cap=4096):
+        r, b, c = np.empty(cap, np.float32), np.empty(cap, np.float32), np.empty(cap, np.uint32)
+        k = node_lib().aslam_node_wait(self._h, _ptr(r, ctypes.c_float), _ptr(b, ctypes.c_float), _ptr(c, ctypes.c_uint32), cap)
+        k = min(k, cap)
+        return r[:k], b[:k], c[:k]
+
+    def replay(self, traj, T=None):
+        """Drive one message-level trajectory through the callbacks; returns poses[T,3], dims[T]."""
+        T = traj.T if T is None else T
+        poses = np.zeros((T, 3))
+        dims = np.zeros(T, np.int32)
+        for t in range(T):
+            if traj.obs_new[t]:
+                k = int(traj.n_obs[t])
+                self.sensor_msg(traj.obs[t, :k, 0], traj.obs[t, :k, 1])
+            if self.odom_msg(traj.odom[t], traj.dt[t]):
+                poses[t] = self.state()[0][:3]
+            dims[t] = self.N
+        return poses, dims

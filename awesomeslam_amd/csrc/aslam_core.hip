@@ -1,0 +1,638 @@
+// aslam_core.hip -- libaslam_core.so: context management + C ABI (include/aslam_core.h) over the gfx950 kernels.
+//
+// Build (see Makefile): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// No CPU fallback exists: without a HIP device every compute entry point returns ASLAM_ERR_HIP.
+#include "../../include/aslam_core.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ekf_small.h"
+#if ASLAM_HAVE_UKF
+#include "ukf_small.h"
+#endif
+
+using namespace aslam;
+
+namespace
+{
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+        g_err = msg;
+        return code;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+        do                                                                                                             \
+        {                                                                                                              \
+                hipError_t e_ = (expr);                                                                                \
+                if (e_ != hipSuccess)                                                                                  \
+                        return fail(ASLAM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+        } while (0)
+} // namespace
+
+struct aslam_ctx
+{
+        aslam_config cfg;
+        int NT;   // 16-wide tiles per dimension
+        int NP;   // padded dimension
+        DevView dv;
+        std::vector<void *> owned; // hipMalloc'ed blocks (state)
+        std::vector<void *> trace_owned;
+        hipStream_t last_stream;
+        int64_t hbm_bytes;
+        size_t lds_bytes;
+        std::string kernel_name;
+};
+
+namespace
+{
+template <typename T> int dev_alloc(aslam_ctx *c, T **p, size_t count, std::vector<void *> &pool)
+{
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, count * sizeof(T)));
+        HIP_TRY(hipMemset(q, 0, count * sizeof(T)));
+        pool.push_back(q);
+        c->hbm_bytes += (int64_t)(count * sizeof(T));
+        *p = static_cast<T *>(q);
+        return ASLAM_OK;
+}
+
+int check_traj(aslam_ctx *c, int traj)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        if (traj < 0 || traj >= c->cfg.batch)
+                return fail(ASLAM_ERR_ARG, "trajectory index out of range");
+        return ASLAM_OK;
+}
+
+int sync_ctx(aslam_ctx *c)
+{
+        HIP_TRY(hipStreamSynchronize(c->last_stream));
+        return ASLAM_OK;
+}
+
+/// initialize() for the whole batch: ekf.cpp:49-71 / ukf.cpp:49-67
+int init_state(aslam_ctx *c)
+{
+        const int B = c->cfg.batch, NP = c->NP;
+        DevView &d = c->dv;
+        HIP_TRY(hipMemset(d.X, 0, sizeof(double) * B * NP));
+        HIP_TRY(hipMemset(d.Z, 0, sizeof(double) * B * NP));
+        HIP_TRY(hipMemset(d.P, 0, sizeof(double) * (size_t)B * NP * NP));
+        HIP_TRY(hipMemset(d.status, 0, sizeof(uint32_t) * B));
+        HIP_TRY(hipMemset(d.sens_n, 0, sizeof(int) * B));
+        HIP_TRY(hipMemset(d.wait_n, 0, sizeof(int) * B));
+        std::vector<int> n(B, 3), fl(B, FLAG_INIT_X | FLAG_INIT_Z);
+        std::vector<double> A(2 * (size_t)B);
+        for (int b = 0; b < B; ++b)
+        {
+                A[2 * b] = 1.0; // A = Identity
+                A[2 * b + 1] = 0.0;
+        }
+        HIP_TRY(hipMemcpy(d.n, n.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.flags, fl.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.A, A.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice));
+        // P = Identity * KP_ROBOT_POSE on the 3 pose entries
+        const double p0 = (double)KP_ROBOT_POSE;
+        std::vector<double> blk((size_t)3 * NP, 0.0);
+        for (int i = 0; i < 3; ++i)
+                blk[(size_t)i * NP + i] = p0;
+        for (int b = 0; b < B; ++b)
+                HIP_TRY(hipMemcpy(d.P + (size_t)b * NP * NP, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
+        return ASLAM_OK;
+}
+
+template <int NT, int MODE>
+int launch_ekf(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa, hipStream_t st)
+{
+        auto kern = ekf_small_kernel<NT, MODE>;
+        const size_t lds = SmallLayout<NT>::total;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMALL_WG), lds, st, c->dv, t0, nsteps, poses, dims, sa);
+        HIP_TRY(hipGetLastError());
+        return ASLAM_OK;
+}
+
+#if ASLAM_HAVE_UKF
+template <int NT, int MODE>
+int launch_ukf(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa, hipStream_t st)
+{
+        auto kern = ukf_small_kernel<NT, MODE>;
+        const size_t lds = UkfLayout<NT>::total;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMALL_WG), lds, st, c->dv, c->ukf, t0, nsteps, poses, dims, sa);
+        HIP_TRY(hipGetLastError());
+        return ASLAM_OK;
+}
+#endif
+
+template <int MODE>
+int launch(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa, hipStream_t st)
+{
+        if (c->cfg.filter == ASLAM_EKF)
+        {
+                switch (c->NT)
+                {
+                case 2:
+                        return launch_ekf<2, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                case 5:
+                        return launch_ekf<5, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                case 9:
+                        return launch_ekf<9, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                }
+        }
+        return fail(ASLAM_ERR_UNSUPPORTED, "no kernel for this filter/size");
+}
+} // namespace
+
+extern "C" {
+
+int aslam_abi_version(void)
+{
+        return ASLAM_ABI_VERSION;
+}
+
+const char *aslam_last_error(void)
+{
+        return g_err.c_str();
+}
+
+int aslam_create(const aslam_config *cfg, aslam_ctx **out)
+{
+        if (!cfg || !out)
+                return fail(ASLAM_ERR_ARG, "null argument");
+        *out = nullptr;
+        if (cfg->filter != ASLAM_EKF && cfg->filter != ASLAM_UKF)
+                return fail(ASLAM_ERR_ARG, "filter must be ASLAM_EKF or ASLAM_UKF");
+        if (cfg->batch < 1 || cfg->max_landmark_count < 4 || cfg->max_obs < 1 || cfg->max_wait < 1)
+                return fail(ASLAM_ERR_ARG, "batch, max_landmark_count, max_obs, max_wait must be positive");
+        if (cfg->dtype != ASLAM_F64)
+                return fail(ASLAM_ERR_UNSUPPORTED, "only ASLAM_F64 is implemented in this round");
+        const int n_max = cfg->max_landmark_count - 1; // growth is refused at N >= MAX_LANDMARK_COUNT
+        const int need = (n_max + 15) / 16;
+        int NT = 0;
+        for (int cand : {2, 5, 9})
+        {
+                if (cand >= need)
+                {
+                        NT = cand;
+                        break;
+                }
+        }
+        if (!NT)
+                return fail(ASLAM_ERR_UNSUPPORTED, "state dimension above 144 needs the multi-workgroup path (not in this round)");
+        if (cfg->max_obs > SMALL_OBS_CAP)
+                return fail(ASLAM_ERR_UNSUPPORTED, "max_obs above 128 is not supported by the single-CU kernels");
+        if (cfg->max_wait > SMALL_WAIT_CAP)
+                return fail(ASLAM_ERR_UNSUPPORTED, "max_wait above 512 is not supported by the single-CU kernels");
+        HIP_TRY(hipSetDevice(cfg->device));
+
+        aslam_ctx *c = new aslam_ctx();
+        c->cfg = *cfg;
+        c->NT = NT;
+        c->NP = 16 * NT;
+        c->last_stream = nullptr;
+        c->hbm_bytes = 0;
+        std::memset(&c->dv, 0, sizeof(c->dv));
+        DevView &d = c->dv;
+        d.B = cfg->batch;
+        d.NP = c->NP;
+        d.dim_cap = cfg->max_landmark_count;
+        d.max_obs = cfg->max_obs;
+        d.max_wait = cfg->max_wait;
+        const size_t B = (size_t)cfg->batch, NP = (size_t)c->NP;
+        int rc = ASLAM_OK;
+        auto A_ = [&](int r) {
+                if (rc == ASLAM_OK)
+                        rc = r;
+        };
+        A_(dev_alloc(c, &d.X, B * NP, c->owned));
+        A_(dev_alloc(c, &d.Z, B * NP, c->owned));
+        A_(dev_alloc(c, &d.P, B * NP * NP, c->owned));
+        A_(dev_alloc(c, &d.A, B * 2, c->owned));
+        A_(dev_alloc(c, &d.n, B, c->owned));
+        A_(dev_alloc(c, &d.flags, B, c->owned));
+        A_(dev_alloc(c, &d.status, B, c->owned));
+        A_(dev_alloc(c, &d.sens, B * cfg->max_obs * 2, c->owned));
+        A_(dev_alloc(c, &d.sens_n, B, c->owned));
+        A_(dev_alloc(c, &d.wait_rb, B * cfg->max_wait * 2, c->owned));
+        A_(dev_alloc(c, &d.wait_cnt, B * cfg->max_wait, c->owned));
+        A_(dev_alloc(c, &d.wait_n, B, c->owned));
+#if ASLAM_HAVE_UKF
+        if (rc == ASLAM_OK && cfg->filter == ASLAM_UKF)
+                rc = ukf_alloc(c);
+#else
+        if (rc == ASLAM_OK && cfg->filter == ASLAM_UKF)
+                rc = fail(ASLAM_ERR_UNSUPPORTED, "library built without the UKF kernels");
+#endif
+        if (rc == ASLAM_OK)
+                rc = init_state(c);
+        if (rc != ASLAM_OK)
+        {
+                std::string keep = g_err;
+                aslam_destroy(c);
+                g_err = keep;
+                return rc;
+        }
+        *out = c;
+        return ASLAM_OK;
+}
+
+int aslam_destroy(aslam_ctx *c)
+{
+        if (!c)
+                return ASLAM_OK;
+        for (void *p : c->owned)
+                (void)hipFree(p);
+        for (void *p : c->trace_owned)
+                (void)hipFree(p);
+        delete c;
+        return ASLAM_OK;
+}
+
+int aslam_reset(aslam_ctx *c)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        int rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        return init_state(c);
+}
+
+int aslam_set_state(aslam_ctx *c, int traj, int n, const double *X, const double *Z, const double *P)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (n < 3 || n >= c->cfg.max_landmark_count || ((n - 3) & 1))
+                return fail(ASLAM_ERR_ARG, "n must be 3 + 2k and below max_landmark_count");
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        const size_t NP = (size_t)c->NP;
+        DevView &d = c->dv;
+        if (X)
+        {
+                std::vector<double> v(NP, 0.0);
+                std::memcpy(v.data(), X, sizeof(double) * n);
+                HIP_TRY(hipMemcpy(d.X + traj * NP, v.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
+        }
+        if (Z)
+        {
+                std::vector<double> v(NP, 0.0);
+                std::memcpy(v.data(), Z, sizeof(double) * n);
+                HIP_TRY(hipMemcpy(d.Z + traj * NP, v.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
+        }
+        if (P)
+        {
+                std::vector<double> v(NP * NP, 0.0);
+                for (int i = 0; i < n; ++i)
+                        std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
+                HIP_TRY(hipMemcpy(d.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
+        }
+        const int fl = 0; // a filter whose state was handed over is past both init flags
+        HIP_TRY(hipMemcpy(d.n + traj, &n, sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.flags + traj, &fl, sizeof(int), hipMemcpyHostToDevice));
+        return ASLAM_OK;
+}
+
+int aslam_grow(aslam_ctx *c, int traj, int n_new, const double *x_seed, const double *z_seed)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        DevView &d = c->dv;
+        int n_old = 0;
+        HIP_TRY(hipMemcpy(&n_old, d.n + traj, sizeof(int), hipMemcpyDeviceToHost));
+        if (n_new <= n_old || ((n_new - n_old) & 1) || !x_seed || !z_seed)
+                return fail(ASLAM_ERR_ARG, "n_new must exceed the current dimension by an even amount; seeds required");
+        if (n_new >= c->cfg.max_landmark_count)
+        {
+                // ekf.cpp:263-268: warn, keep N, drop the landmarks
+                uint32_t st = 0;
+                HIP_TRY(hipMemcpy(&st, d.status + traj, sizeof(st), hipMemcpyDeviceToHost));
+                st |= ASLAM_ST_GROWTH_REFUSED;
+                HIP_TRY(hipMemcpy(d.status + traj, &st, sizeof(st), hipMemcpyHostToDevice));
+                return ASLAM_OK;
+        }
+        const size_t NP = (size_t)c->NP;
+        const int k = n_new - n_old;
+        HIP_TRY(hipMemcpy(d.X + traj * NP + n_old, x_seed, sizeof(double) * k, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.Z + traj * NP + n_old, z_seed, sizeof(double) * k, hipMemcpyHostToDevice));
+        // conservativeResizeLike(Identity * UKF_KP_LANDMARK_POSE): new rows/columns
+        double *Pg = d.P + traj * NP * NP;
+        std::vector<double> row(NP, 0.0);
+        for (int i = 0; i < n_old; ++i) // new columns of old rows are already zero padding: nothing to do
+                (void)i;
+        for (int i = n_old; i < n_new; ++i)
+        {
+                std::fill(row.begin(), row.end(), 0.0);
+                row[i] = (double)KP_LANDMARK_POSE;
+                HIP_TRY(hipMemcpy(Pg + (size_t)i * NP, row.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMemcpy(d.n + traj, &n_new, sizeof(int), hipMemcpyHostToDevice));
+        return ASLAM_OK;
+}
+
+int aslam_ekf_step(aslam_ctx *c, int traj, float vx, float az, float dt, const double *Z, double a00, double a10,
+                   double *X_out, void *stream)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (c->cfg.filter != ASLAM_EKF)
+                return fail(ASLAM_ERR_STATE, "context was created for the UKF");
+        if (!Z)
+                return fail(ASLAM_ERR_ARG, "Z is required");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        c->last_stream = st;
+        DevView &d = c->dv;
+        int n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, d.n + traj, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const size_t NP = (size_t)c->NP;
+        const double A[2] = {a00, a10};
+        HIP_TRY(hipMemcpyAsync(d.Z + traj * NP, Z, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.A + 2 * traj, A, sizeof(A), hipMemcpyHostToDevice, st));
+        StepArgs sa{traj, vx, az, dt};
+        rc = launch<MODE_STEP>(c, 1, 0, 1, nullptr, nullptr, sa, st);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (X_out)
+        {
+                HIP_TRY(hipMemcpyAsync(X_out, d.X + traj * NP, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+        }
+        return ASLAM_OK;
+}
+
+int aslam_ukf_step(aslam_ctx *c, int traj, float vx, float az, float dt, const double *Z, double *X_out, void *stream)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (c->cfg.filter != ASLAM_UKF)
+                return fail(ASLAM_ERR_STATE, "context was created for the EKF");
+        if (!Z)
+                return fail(ASLAM_ERR_ARG, "Z is required");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        c->last_stream = st;
+        DevView &d = c->dv;
+        int n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, d.n + traj, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const size_t NP = (size_t)c->NP;
+        HIP_TRY(hipMemcpyAsync(d.Z + traj * NP, Z, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        StepArgs sa{traj, vx, az, dt};
+        rc = launch<MODE_STEP>(c, 1, 0, 1, nullptr, nullptr, sa, st);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (X_out)
+        {
+                HIP_TRY(hipMemcpyAsync(X_out, d.X + traj * NP, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+        }
+        return ASLAM_OK;
+}
+
+int aslam_set_trace(aslam_ctx *c, const aslam_trace *tr)
+{
+        if (!c || !tr)
+                return fail(ASLAM_ERR_ARG, "null argument");
+        if (tr->T < 1 || tr->max_obs != c->cfg.max_obs)
+                return fail(ASLAM_ERR_ARG, "trace must have T >= 1 and the context's max_obs");
+        if (!tr->pose || !tr->yaw || !tr->twist || !tr->dt || !tr->obs_new || !tr->n_obs || !tr->obs)
+                return fail(ASLAM_ERR_ARG, "trace arrays must all be given");
+        int rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        for (void *p : c->trace_owned)
+                (void)hipFree(p);
+        c->trace_owned.clear();
+        DevView &d = c->dv;
+        d.T = tr->T;
+        const size_t BT = (size_t)c->cfg.batch * (size_t)tr->T;
+        if (tr->is_device)
+        {
+                d.tr_pose = tr->pose;
+                d.tr_yaw = tr->yaw;
+                d.tr_twist = tr->twist;
+                d.tr_dt = tr->dt;
+                d.tr_new = tr->obs_new;
+                d.tr_nobs = tr->n_obs;
+                d.tr_obs = tr->obs;
+                return ASLAM_OK;
+        }
+        auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+                void *q = nullptr;
+                HIP_TRY(hipMalloc(&q, bytes));
+                c->trace_owned.push_back(q);
+                HIP_TRY(hipMemcpy(q, src, bytes, hipMemcpyHostToDevice));
+                *dst = q;
+                return ASLAM_OK;
+        };
+        const void *p = nullptr;
+#define UP(field, src, bytes)                                                                                          \
+        rc = up(src, bytes, &p);                                                                                       \
+        if (rc != ASLAM_OK)                                                                                            \
+                return rc;                                                                                             \
+        d.field = static_cast<decltype(d.field)>(p);
+        UP(tr_pose, tr->pose, BT * 2 * sizeof(double));
+        UP(tr_yaw, tr->yaw, BT * sizeof(float));
+        UP(tr_twist, tr->twist, BT * 2 * sizeof(double));
+        UP(tr_dt, tr->dt, BT * sizeof(float));
+        UP(tr_new, tr->obs_new, BT * sizeof(uint8_t));
+        UP(tr_nobs, tr->n_obs, BT * sizeof(int32_t));
+        UP(tr_obs, tr->obs, BT * (size_t)tr->max_obs * 2 * sizeof(float));
+#undef UP
+        return ASLAM_OK;
+}
+
+int aslam_replay(aslam_ctx *c, int64_t t0, int64_t nsteps, double *poses_out, int32_t *dims_out, void *stream)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        if (!c->dv.tr_pose)
+                return fail(ASLAM_ERR_STATE, "no trace bound (aslam_set_trace)");
+        if (t0 < 0 || nsteps < 1 || t0 + nsteps > c->dv.T || nsteps > 0x7fffffff)
+                return fail(ASLAM_ERR_ARG, "step range outside the bound trace");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        c->last_stream = st;
+        StepArgs sa{0, 0.f, 0.f, 0.f};
+        return launch<MODE_REPLAY>(c, c->cfg.batch, t0, (int)nsteps, poses_out, dims_out, sa, st);
+}
+
+int aslam_get_dim(aslam_ctx *c, int traj, int *n)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (!n)
+                return fail(ASLAM_ERR_ARG, "null output");
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        HIP_TRY(hipMemcpy(n, c->dv.n + traj, sizeof(int), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+int aslam_get_state(aslam_ctx *c, int traj, double *X, double *Z, double *P)
+{
+        int n = 0;
+        int rc = aslam_get_dim(c, traj, &n);
+        if (rc != ASLAM_OK)
+                return rc;
+        const size_t NP = (size_t)c->NP;
+        DevView &d = c->dv;
+        if (X)
+                HIP_TRY(hipMemcpy(X, d.X + traj * NP, sizeof(double) * n, hipMemcpyDeviceToHost));
+        if (Z)
+                HIP_TRY(hipMemcpy(Z, d.Z + traj * NP, sizeof(double) * n, hipMemcpyDeviceToHost));
+        if (P)
+                HIP_TRY(hipMemcpy2D(P, sizeof(double) * n, d.P + traj * NP * NP, sizeof(double) * NP, sizeof(double) * n, n,
+                                    hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+int aslam_get_A(aslam_ctx *c, int traj, double *a00, double *a10)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        double A[2];
+        HIP_TRY(hipMemcpy(A, c->dv.A + 2 * traj, sizeof(A), hipMemcpyDeviceToHost));
+        if (a00)
+                *a00 = A[0];
+        if (a10)
+                *a10 = A[1];
+        return ASLAM_OK;
+}
+
+int aslam_get_landmarks(aslam_ctx *c, int traj, double *x, double *y, int *n_landmarks)
+{
+        int n = 0;
+        int rc = aslam_get_dim(c, traj, &n);
+        if (rc != ASLAM_OK)
+                return rc;
+        std::vector<double> X(n);
+        HIP_TRY(hipMemcpy(X.data(), c->dv.X + (size_t)traj * c->NP, sizeof(double) * n, hipMemcpyDeviceToHost));
+        const int L = (n - 3) / 2;
+        for (int i = 0; i < L; ++i)
+        {
+                if (x)
+                        x[i] = X[3 + 2 * i];
+                if (y)
+                        y[i] = X[4 + 2 * i];
+        }
+        if (n_landmarks)
+                *n_landmarks = L;
+        return ASLAM_OK;
+}
+
+int aslam_get_wait(aslam_ctx *c, int traj, float *range, float *bearing, uint32_t *count, int cap, int *size)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        DevView &d = c->dv;
+        int wn = 0;
+        HIP_TRY(hipMemcpy(&wn, d.wait_n + traj, sizeof(int), hipMemcpyDeviceToHost));
+        if (size)
+                *size = wn;
+        const int k = wn < cap ? wn : cap;
+        if (k > 0)
+        {
+                std::vector<float> rb(2 * (size_t)k);
+                std::vector<uint32_t> cn(k);
+                HIP_TRY(hipMemcpy(rb.data(), d.wait_rb + (size_t)traj * d.max_wait * 2, sizeof(float) * 2 * k, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(cn.data(), d.wait_cnt + (size_t)traj * d.max_wait, sizeof(uint32_t) * k, hipMemcpyDeviceToHost));
+                for (int i = 0; i < k; ++i)
+                {
+                        if (range)
+                                range[i] = rb[2 * i];
+                        if (bearing)
+                                bearing[i] = rb[2 * i + 1];
+                        if (count)
+                                count[i] = cn[i];
+                }
+        }
+        return ASLAM_OK;
+}
+
+int aslam_get_status(aslam_ctx *c, int traj, uint32_t *status_bits)
+{
+        int rc = check_traj(c, traj);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (!status_bits)
+                return fail(ASLAM_ERR_ARG, "null output");
+        rc = sync_ctx(c);
+        if (rc != ASLAM_OK)
+                return rc;
+        HIP_TRY(hipMemcpy(status_bits, c->dv.status + traj, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+int aslam_get_layout(aslam_ctx *c, int *padded_dim, int64_t *hbm_bytes)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        if (padded_dim)
+                *padded_dim = c->NP;
+        if (hbm_bytes)
+                *hbm_bytes = c->hbm_bytes;
+        return ASLAM_OK;
+}
+
+int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *block, int *lds_bytes)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        char buf[96];
+        size_t lds = 0;
+        if (c->cfg.filter == ASLAM_EKF)
+        {
+                std::snprintf(buf, sizeof(buf), "ekf_small_kernel<%d,0>", c->NT);
+                lds = c->NT == 2 ? SmallLayout<2>::total : c->NT == 5 ? SmallLayout<5>::total : SmallLayout<9>::total;
+        }
+#if ASLAM_HAVE_UKF
+        else
+        {
+                std::snprintf(buf, sizeof(buf), "ukf_small_kernel<%d,0>", c->NT);
+                lds = c->NT == 2 ? UkfLayout<2>::total : c->NT == 5 ? UkfLayout<5>::total : UkfLayout<9>::total;
+        }
+#endif
+        if (name && name_cap > 0)
+        {
+                std::strncpy(name, buf, name_cap - 1);
+                name[name_cap - 1] = 0;
+        }
+        if (grid)
+                *grid = c->cfg.batch;
+        if (block)
+                *block = SMALL_WG;
+        if (lds_bytes)
+                *lds_bytes = (int)lds;
+        return ASLAM_OK;
+}
+
+} // extern "C"
