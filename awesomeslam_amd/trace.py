@@ -20,8 +20,9 @@ properties of the reference shape it:
     sensor range is unlimited (`sensor_range` restricts it for divergence/edge tests only);
   * a landmark is promoted only after 10 sightings from (nearly) the same place, because the wait-list
     keeps sensor-frame readings and re-projects them from the current pose (ekf.cpp:217-253): the
-    warm-up is therefore `stages` stops of 14 callbacks, and the landmarks are "born" (switched on) in
-    `stages` groups, one per stop, so that the state grows in several steps (ekf.cpp:255-290).
+    warm-up is therefore `stages` x 14 callbacks at rest at the start pose, and the landmarks are "born"
+    (switched on) in `stages` groups, one per 14 callbacks, so that the state grows in several steps
+    (ekf.cpp:255-290).
 After the warm-up the robot drives on with arcs, exact straights (wz = 0), |wz| <= 0.001 segments, stops
 and spins so that every branch of common.h:52-62 and ekf.cpp:206 is taken.
 
@@ -107,6 +108,11 @@ class Trajectory:
     def max_obs(self):
         return self.obs.shape[1]
 
+    def slice(self, t0, t1):
+        """Callbacks t0 .. t1-1 as a trajectory of their own."""
+        return Trajectory(self.odom[t0:t1], self.dt[t0:t1], self.obs_new[t0:t1], self.n_obs[t0:t1], self.obs[t0:t1],
+                          self.landmarks, None if self.truth is None else self.truth[t0:t1], self.warmup)
+
 
 def loop_radius(L):
     """Radius of the reference circle so that the inner ring holds L/4 landmarks >= 1.7 m apart."""
@@ -147,7 +153,7 @@ def _landmarks(L, rng, layout="ring"):
     return lm[rng.permutation(L)]
 
 
-def _schedule(T, L, rng, stages):
+def _schedule(T, L, rng, stages, warm_hop=0):
     """Pre-drawn control schedule: mode[t], v[t], wfix[t], warm-up length, birth time of each stage.
     mode: 0 arc (feedback), 1 exact straight, 2 tiny |wz| <= 0.001, 3 stop, 4 spin (wfix = turn rate)."""
     mode = np.zeros(T, np.int8)
@@ -156,14 +162,19 @@ def _schedule(T, L, rng, stages):
     t = 0
     births = []
     for g in range(stages):
-        segs = ((STOP_STEPS, 3, 0.0),) if g == 0 else ((12, 0, 0.15), (STOP_STEPS, 3, 0.0))
-        for n, m, vv in segs:
-            if m == 3:
-                births.append(t)
-            n = min(n, T - t)
-            mode[t : t + n] = m
-            v[t : t + n] = vv
+        # every warm-up stop is at the start pose: a wait-list entry is a sensor-frame reading that the
+        # reference re-projects from the CURRENT pose (ekf.cpp:229-233), so a stop somewhere else would let
+        # old entries capture the sightings of new landmarks
+        # (warm_hop > 0 moves between the stops anyway: a stress case that fills the wait-list with junk)
+        if g > 0 and warm_hop > 0:
+            n = min(warm_hop, T - t)
+            mode[t : t + n] = 0
+            v[t : t + n] = 0.15
             t += n
+        births.append(t)
+        n = min(STOP_STEPS, T - t)
+        mode[t : t + n] = 3
+        t += n
     warm = t
     while t < T:
         u = rng.random()
@@ -196,7 +207,7 @@ def _wrap(a):
 
 def make_traces(L, T, B=1, seed=0, dt_mode="fixed", sensor_every=1, stages=3, max_obs=None,
                 odom_sigma=0.01, obs_sigma=0.02, first_traj=0, sensor_range=SENSOR_RANGE, layout="field",
-                yaw_sigma=0.002, bearing_sigma=0.002):
+                yaw_sigma=0.002, bearing_sigma=0.002, warm_hop=0):
     """Generate B trajectories (indices first_traj .. first_traj+B-1 of stream `seed`).
 
     layout "field" (default; both filters): landmarks on a grid east of a small loop.  layout "ring"
@@ -205,7 +216,7 @@ def make_traces(L, T, B=1, seed=0, dt_mode="fixed", sensor_every=1, stages=3, ma
     Rc = FIELD_LOOP_RADIUS if layout == "field" else loop_radius(L)
     rngs = [np.random.default_rng([seed, first_traj + b, L]) for b in range(B)]
     lms = np.stack([_landmarks(L, r, layout) for r in rngs])  # [B, L, 2]
-    sched = [_schedule(T, L, r, stages) for r in rngs]
+    sched = [_schedule(T, L, r, stages, warm_hop) for r in rngs]
     mode = np.stack([s[0] for s in sched])
     vcmd = np.stack([s[1] for s in sched])
     wfix = np.stack([s[2] for s in sched])

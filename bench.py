@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py -- filter-steps/s of the MI355X-native EKF/UKF-SLAM core on synthetic trajectories.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ekf64|ukf64|ekf8] [--batch B] [--chunk C]
+
+One bench "step" = one replay launch = `chunk` consecutive callbacks (sensor message + odom message:
+association, growth bookkeeping, predict, update) for each of the `batch` independent trajectories held by a
+GPU.  The trace is already resident in HBM when the timed region starts.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank owns `batch` trajectories of its own (weak scaling) and the
+only communication is one all_gather of the pose streams at the end of the timed region.
+Prints ONE JSON line (rank 0).  The CPU oracle is used for the `cpu_baseline` leg and for nothing else.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from awesomeslam_amd import dist as adist  # noqa: E402
+from awesomeslam_amd import trace as tg  # noqa: E402
+from awesomeslam_amd.core import Core  # noqa: E402
+
+WORKLOADS = {
+    # name: (filter, landmarks, BASELINE.json config it corresponds to)
+    "ekf64": ("ekf", 64, "configs[1]: EKF, 64 landmarks (n=131), fp64"),
+    "ukf64": ("ukf", 64, "configs[2]: UKF, 64 landmarks (n=131), fp64"),
+    "ekf8": ("ekf", 8, "configs[0] geometry on the GPU: EKF, 8 landmarks (n=19), fp64"),
+}
+# fp64 peak: 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz = 78.6 TFLOP/s, for v_fma_f64 and v_mfma_f64 alike
+# (= half of the 157.3 TFLOP/s FP32 row of MI355X_MICROARCH.md, which lists no fp64 row of its own)
+PEAK_F64_TFLOPS = 78.6
+
+
+def algorithmic_flops(kind, n):
+    """reference-equivalent minimum per callback."""
+    return (2.0 + 1.0 / 3.0) * n ** 3 if kind == "ekf" else 10.7 * n ** 3
+
+
+def cpu_baseline(kind, L, seed, prologue, sample):
+    """The C++ oracle (Eigen-free restatement of the reference node, -O2, one core) on a bounded sample of the
+    same workload: trajectory 0, `sample` steady-state callbacks after the warm-up prologue."""
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(L, prologue + sample, B=1, seed=seed)[0]
+    o = CFilter(kind, tg.dim_cap(L))
+    o.replay(tr.slice(0, prologue))
+    t0 = time.perf_counter()
+    o.replay(tr.slice(prologue, prologue + sample))
+    el = time.perf_counter() - t0
+    return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port",
+            "sample": f"trajectory 0 of the same seed, {sample} steady-state callbacks after a {prologue}-callback "
+                      f"warm-up, N={o.N}; oracle/aslam_oracle.cpp (as-coded 18 n^3 algebra), g++ -O2, 1 thread, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ekf64", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=256, help="trajectories per GPU")
+    ap.add_argument("--chunk", type=int, default=500, help="callbacks per launch (= per bench step)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="callbacks timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local = adist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the filter core has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    kind, L, cfg_name = WORKLOADS[args.workload]
+    n_full = tg.full_dim(L)
+    B, C, K, W = args.batch, args.chunk, args.steps, args.warmup
+    prologue = 64  # callbacks: the 42-callback warm-up in which the state grows to n_full, rounded up
+    T = prologue + (W + K) * C
+
+    # ---- synthetic input, distinct per trajectory and per rank, resident in HBM before timing starts
+    t_gen = time.time()
+    tr = tg.make_traces(L, T, B=B, seed=args.seed, first_traj=rank * B)
+    t_gen = time.time() - t_gen
+    core = Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(512, 2 * L + 64), device=local)
+    core.set_trace(tr)
+    stream = torch.cuda.current_stream().cuda_stream
+    poses = torch.zeros((K, B, C, 3), dtype=torch.float64, device=dev)
+    scratch = torch.zeros((B, max(C, prologue), 3), dtype=torch.float64, device=dev)
+    dims = torch.zeros((B, prologue), dtype=torch.int32, device=dev)
+
+    core.replay(0, prologue, scratch.data_ptr(), dims.data_ptr(), stream)
+    torch.cuda.synchronize()
+    for b in range(0, B, max(1, B // 8)):
+        if core.dim(b) != n_full or core.status(b) != 0:
+            raise SystemExit(f"trajectory {b}: N={core.dim(b)} (want {n_full}), status={core.status(b)} after the warm-up")
+    for w in range(W):
+        core.replay(prologue + w * C, C, scratch.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    adist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        core.replay(prologue + (W + k) * C, C, poses[k].data_ptr(), None, stream)
+        ev[k][1].record()
+    all_poses = adist.gather_poses(poses.permute(1, 0, 2, 3).reshape(B, K * C, 3))  # the one collective: poses, at the end
+    torch.cuda.synchronize()
+    adist.barrier()
+    el = time.perf_counter() - t0
+    el = adist.max_over_ranks(el, dev if world > 1 else "cpu")
+    launch_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_s = float(np.mean(launch_ms)) * 1e-3
+
+    ok = all(core.dim(b) == n_full and core.status(b) == 0 for b in range(0, B, max(1, B // 8)))
+    finite = bool(torch.isfinite(all_poses).all().item())
+    if not (ok and finite):
+        raise SystemExit("bench: a filter left its steady state (dimension/status/non-finite pose)")
+
+    if rank == 0:
+        total_steps = world * B * C * K
+        flops_launch = algorithmic_flops(kind, n_full) * B * C
+        achieved = flops_launch / kernel_s / 1e12
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        info = core.kernel_info()
+        out = {
+            "metric": "EKF/UKF filter-steps/s @ N_landmarks", "value": total_steps / el, "unit": "filter-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} = {cfg_name}", "landmarks": L, "state_dim": n_full,
+                       "trajectories_per_gpu": B, "callbacks_per_step": C, "parallelism": f"trajectory-sharded x{world}",
+                       "kernel": info["name"], "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
+                       "trace_gen_s": round(t_gen, 1)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kernel_s * 1e3,
+                         "note": "achieved = SURVEY 8(d) algorithmic flops/callback x callbacks x trajectories per launch / "
+                                 "mean launch duration (HIP events on the launch stream); peak = fp64 FMA/MFMA rate"},
+        }
+        sample = args.cpu_sample
+        if sample is None:
+            sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000}[args.workload]
+        if world == 1 and sample > 0:
+            out["cpu_baseline"] = cpu_baseline(kind, L, args.seed, prologue, sample)
+        print(json.dumps(out))
+    adist.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""The C-ABI libraries load and export every symbol the headers declare; no compute without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from awesomeslam_amd import core
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    return sorted(set(re.findall(r"\b(aslam_[A-Za-z_0-9]+)\s*\(", txt)))
+
+
+def test_core_exports_every_declared_symbol(built):
+    names = declared(os.path.join(ROOT, "include", "aslam_core.h"))
+    assert sorted(names) == sorted(core.CORE_SYMBOLS)
+    lib = ctypes.CDLL(os.path.join(ROOT, "awesomeslam_amd", "csrc", "libaslam_core.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.aslam_abi_version() == 1
+
+
+def test_node_exports_every_declared_symbol(built):
+    names = [n for n in declared(os.path.join(ROOT, "awesomeslam_amd", "csrc", "host", "aslam_node.h"))
+             if n.startswith(("aslam_node", "aslam_host"))]
+    assert sorted(names) == sorted(core.NODE_SYMBOLS)
+    lib = core.node_lib()
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_argument_errors_are_reported(built):
+    lib = core.core_lib()
+    h = ctypes.c_void_p()
+    cfg = core.Config(7, 0, 30, 1, 8, 8, 0, 0)          # bad filter id
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"filter" in lib.aslam_last_error()
+    cfg = core.Config(0, 0, 30, 0, 8, 8, 0, 0)          # batch 0
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg = core.Config(0, 1, 30, 1, 8, 8, 0, 0)          # fp32: not in this round
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -3
+    cfg = core.Config(0, 0, 2000, 1, 8, 8, 0, 0)        # n > 144: multi-workgroup path, not in this round
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -3
+
+
+def test_no_cpu_fallback(built):
+    """Without a HIP device the product path fails loudly instead of computing somewhere else."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(core.AslamError):
+        core.Core("ekf", 30, batch=1, max_obs=8, max_wait=16)
+    with pytest.raises(core.AslamError):
+        core.Node("ekf", 30)
+
+
+def test_host_narrowing_matches_reference_casts(built):
+    """aslam_host_narrow_odom = updateZandA's message reads (ekf.cpp:139-142): yaw is quat2euler in binary32."""
+    rng = np.random.default_rng(0)
+    yaw = rng.uniform(-3.1, 3.1, 64)
+    odom = np.zeros((4, 16, 8))
+    odom[..., 0:2] = rng.normal(size=(4, 16, 2))
+    odom[..., 2] = np.cos(yaw / 2).reshape(4, 16)
+    odom[..., 5] = np.sin(yaw / 2).reshape(4, 16)
+    odom[..., 6:8] = rng.normal(size=(4, 16, 2))
+    pose, y32, twist = core.narrow_odom(odom)
+    assert pose.shape == (4, 16, 2) and y32.dtype == np.float32 and twist.shape == (4, 16, 2)
+    assert np.array_equal(pose, odom[..., 0:2]) and np.array_equal(twist, odom[..., 6:8])
+    assert np.abs(y32.reshape(-1) - yaw).max() < 1e-6
+    # same function as the oracle's quat2euler (both call the host libm's atan2f)
+    from oracle import c_oracle
+    for k in range(8):
+        o = odom.reshape(-1, 8)[k]
+        assert y32.reshape(-1)[k] == c_oracle.quat2euler(o[2], o[3], o[4], o[5])

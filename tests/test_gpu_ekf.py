@@ -1,0 +1,233 @@
+"""-m gpu: the HIP EKF path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): state/covariance within 1e-6 relative (norm-wise, util.rel_err); landmark-index
+bookkeeping -- Z, state dimension per callback, wait-list -- bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from awesomeslam_amd import trace as tg
+from util import REL_TOL, rel_err, sub_trajectory
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_replay(kind, tr, cap, chunk=None, max_wait=256):
+    import torch
+    from awesomeslam_amd.core import Core
+
+    B, T = tr.B, tr.T
+    core = Core(kind, cap, batch=B, max_obs=tr.max_obs, max_wait=max_wait)
+    core.set_trace(tr)
+    chunk = T if chunk is None else chunk
+    poses = np.zeros((B, T, 3))
+    dims = np.zeros((B, T), np.int32)
+    for t0 in range(0, T, chunk):
+        k = min(chunk, T - t0)
+        p = torch.zeros((B, k, 3), dtype=torch.float64, device="cuda")
+        d = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+        core.replay(t0, k, p.data_ptr(), d.data_ptr())
+        torch.cuda.synchronize()
+        poses[:, t0:t0 + k] = p.cpu().numpy()
+        dims[:, t0:t0 + k] = d.cpu().numpy()
+    return core, poses, dims
+
+
+def assert_parity(core, b, poses, dims, oracle, po, do, tol=REL_TOL):
+    Xo, Zo, Po = oracle.state()
+    X, Z, P = core.state(b)
+    assert np.array_equal(dims, do), "state dimension per callback must be bit-exact"
+    assert np.array_equal(Z, Zo), "Z (association result) must be bit-exact"
+    w, wo = core.wait_list(b), oracle.wait_list()
+    for a, c in zip(w, wo):
+        assert np.array_equal(a, c), "wait-list must be bit-exact"
+    if core.filter == "ekf":
+        assert core.A(b) == oracle.A()
+    errs = rel_err(poses, po), rel_err(X, Xo), rel_err(P, Po)
+    assert max(errs) < tol, errs
+    return errs
+
+
+CASES = [
+    ("L5", 5, 1000, dict(seed=21), 30, None),                       # BASELINE config 1 as named, shipped cap
+    ("L8", 8, 1000, dict(seed=22), 30, 137),                         # config 1 as shipped (8 landmarks); chunked launches
+    ("L13-4stages", 13, 500, dict(seed=23, stages=4), 30, None),
+    ("L8-rewalk-randomdt", 8, 500, dict(seed=24, sensor_every=3, dt_mode="random"), 30, 50),
+    ("L8-junk-wait-list", 8, 400, dict(seed=25, warm_hop=12, layout="ring", sensor_range=6.0), 30, None),
+    ("L14-cap-refusal", 14, 300, dict(seed=26, stages=2), 30, None),
+    ("L20", 20, 300, dict(seed=27), None, None),                     # NT = 5 kernel
+    ("L64", 64, 400, dict(seed=28), None, 150),                      # BASELINE config 2 geometry (n = 131)
+]
+
+
+@pytest.mark.parametrize("name,L,T,kw,cap,chunk", CASES, ids=[c[0] for c in CASES])
+def test_replay_parity(name, L, T, kw, cap, chunk, built):
+    from oracle.c_oracle import CFilter
+
+    cap = tg.dim_cap(L) if cap is None else cap
+    B = 2
+    tr = tg.make_traces(L, T, B=B, **kw)
+    core, poses, dims = gpu_replay("ekf", tr, cap, chunk)
+    for b in range(B):
+        o = CFilter("ekf", cap)
+        po, do = o.replay(tr[b])
+        errs = assert_parity(core, b, poses[b], dims[b], o, po, do)
+        print(f"{name} b={b} N={core.dim(b)} rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        st = core.status(b)
+        assert (st & 1) == (1 if "cap-refusal" in name else 0)
+        assert st & ~1 == 0
+
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ekf_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_golden(path, built):
+    z = np.load(path)
+    tr = tg.Trace(z["odom"][None], z["dt"][None], z["obs_new"][None], z["n_obs"][None], z["obs"][None],
+                  np.zeros((1, 1, 2)), np.zeros((1, z["odom"].shape[0], 3)))
+    core, poses, dims = gpu_replay("ekf", tr, int(z["cap"]), max_wait=512)
+    X, Z, P = core.state(0)
+    assert np.array_equal(dims[0], z["dims"]) and np.array_equal(Z, z["Z"])
+    w = core.wait_list(0)
+    assert np.array_equal(w[0], z["wait_range"]) and np.array_equal(w[1], z["wait_bearing"]) and np.array_equal(w[2], z["wait_count"])
+    assert tuple(z["A"]) == core.A(0)
+    assert max(rel_err(poses[0], z["poses"]), rel_err(X, z["X"]), rel_err(P, z["P"])) < REL_TOL
+
+
+@pytest.mark.parametrize("L,T,kw", [(5, 150, dict(seed=31)), (8, 200, dict(seed=32, sensor_every=2)), (13, 120, dict(seed=33, stages=1))])
+def test_per_callback_seam_host_mirror(L, T, kw, built):
+    """aslam::EKFSlam host mirror (C++): association/growth on the host, P/X/slam() on the GPU."""
+    from awesomeslam_amd.core import Node
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(L, T, B=1, **kw)[0]
+    node = Node("ekf", 30)
+    pn, dn = node.replay(tr)
+    o = CFilter("ekf", 30)
+    po, do = o.replay(tr)
+    Xo, Zo, Po = o.state()
+    X, Z, a00, a10 = node.state()
+    assert np.array_equal(dn, do) and np.array_equal(Z, Zo) and (a00, a10) == o.A()
+    for a, c in zip(node.wait_list(), o.wait_list()):
+        assert np.array_equal(a, c)
+    assert max(rel_err(pn, po), rel_err(X, Xo), rel_err(node.P(), Po)) < REL_TOL
+
+
+def test_node_clock_delta_time(built):
+    """cbOdom derives delta_time = min(now - last_time, 1.0) with a float last_time (ekf.cpp:80-81)."""
+    from awesomeslam_amd.core import Node
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(5, 40, B=1, seed=34)[0]
+    node, o = Node("ekf", 30), CFilter("ekf", 30)
+    now, last = 100.25, np.float32(0.0)
+    for t in range(tr.T):
+        k = int(tr.n_obs[t])
+        node.sensor_msg(tr.obs[t, :k, 0], tr.obs[t, :k, 1])
+        o.sensor_msg(tr.obs[t, :k, 0], tr.obs[t, :k, 1])
+        now += 0.37 if t % 3 else 1.9
+        dt = np.float32(min(now - float(last), 1.0))
+        last = np.float32(now)
+        node.odom_msg_now(tr.odom[t], now)
+        o.odom_msg(*tr.odom[t], dt)
+    assert rel_err(node.state()[0], o.X) < REL_TOL
+
+
+@pytest.mark.parametrize("n", [3, 13, 29, 61, 131])
+def test_single_slam_on_synthetic_state(n, built):
+    """Kernel-level: one slam() on a random SPD covariance (no trace), per-callback seam."""
+    from awesomeslam_amd.core import Core
+    from oracle.c_oracle import CFilter
+
+    rng = np.random.default_rng(n)
+    L = (n - 3) // 2
+    X = np.concatenate([[0.3, -0.2, 0.4], (12 + 3 * rng.normal(size=(L, 2))).ravel()])
+    A = rng.normal(size=(n, n)) * 0.05
+    P = A @ A.T + np.eye(n) * 0.01
+    Z = X.copy()
+    for i in range(L):
+        dx, dy = X[3 + 2 * i] - X[0], X[4 + 2 * i] - X[1]
+        Z[3 + 2 * i] = np.float32(np.hypot(dx, dy) + 0.01 * rng.normal())
+        Z[4 + 2 * i] = np.float32(np.arctan2(dy, dx) - X[2] + 0.01 * rng.normal())
+    cap = max(30, n + 1)
+    core = Core("ekf", cap, batch=2, max_obs=4, max_wait=4)
+    o = CFilter("ekf", cap)
+    core.set_state(1, n, X, Z, P)
+    o.set_state(n, X, Z, P, 0.07, -0.03)
+    for vx, az, dt in ((0.2, 0.1, 1.0), (0.15, 0.0, 0.5), (0.0, 0.0, 1.0)):
+        Xg = core.ekf_step(1, vx, az, dt, Z, 0.07, -0.03)
+        o.slam(vx, az, dt)
+        Xo, _, Po = o.state()
+        assert rel_err(Xg, Xo) < REL_TOL
+    _, _, Pg = core.state(1)
+    assert rel_err(Pg, Po) < REL_TOL
+    assert core.dim(0) == 3                      # the neighbouring filter of the batch is untouched
+    assert np.array_equal(core.state(0)[2], np.eye(3) * float(np.float32(0.001)))
+
+
+def test_edge_messages(built):
+    """Callbacks before any sensor message are dropped; empty messages; over-long messages are flagged."""
+    from awesomeslam_amd.core import ST_OBS_OVERFLOW
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(5, 60, B=1, seed=35)
+    tr.obs_new[0, :3] = 0                         # three odom messages before the first sensor message
+    tr.n_obs[0, 20:23] = 0                        # empty sensor messages
+    core, poses, dims = gpu_replay("ekf", tr, 30)
+    o = CFilter("ekf", 30)
+    po, do = o.replay(tr[0])
+    assert np.all(poses[0, :3] == 0)
+    assert_parity(core, 0, poses[0], dims[0], o, po, do)
+    assert core.status(0) == 0
+    # a message longer than the context's max_obs
+    tr2 = tg.make_traces(5, 20, B=1, seed=36)
+    tr2.n_obs[0, 5] = tr2.max_obs + 3
+    core2, _, _ = gpu_replay("ekf", tr2, 30)
+    assert core2.status(0) & ST_OBS_OVERFLOW
+
+
+def test_reset_and_rerun_is_bitwise_reproducible(built):
+    tr = tg.make_traces(8, 200, B=2, seed=37)
+    core, p1, d1 = gpu_replay("ekf", tr, 30)
+    X1, Z1, P1 = core.state(1)
+    core.reset()
+    assert core.dim(1) == 3
+    import torch
+    p = torch.zeros((2, 200, 3), dtype=torch.float64, device="cuda")
+    core.replay(0, 200, p.data_ptr(), None)
+    torch.cuda.synchronize()
+    X2, Z2, P2 = core.state(1)
+    assert np.array_equal(p.cpu().numpy(), p1) and np.array_equal(X1, X2) and np.array_equal(P1, P2)
+
+
+def test_full_size_config2_properties(built):
+    """BASELINE config 2 at full length (64 landmarks, 100k callbacks): oracle parity on a prefix, then
+    size-independent properties of the final state, and one-launch == chunked-launches bitwise."""
+    from oracle.c_oracle import CFilter
+
+    L, T, B = 64, 100_000, 4
+    tr = tg.make_traces(L, T, B=B, seed=2)
+    core, poses, dims = gpu_replay("ekf", tr, tg.dim_cap(L), chunk=10_000)
+    pre = 1500
+    o = CFilter("ekf", tg.dim_cap(L))
+    po, do = o.replay(sub_trajectory(tr[0], 0, pre))
+    assert np.array_equal(dims[0, :pre], do)
+    assert rel_err(poses[0, :pre], po) < REL_TOL
+    for b in range(B):
+        assert core.dim(b) == tg.full_dim(L) and core.status(b) == 0
+        X, Z, P = core.state(b)
+        assert np.isfinite(P).all()
+        assert np.abs(P - P.T).max() < 1e-9 * np.abs(P).max()            # (I-KH)P stays symmetric to rounding
+        assert np.linalg.eigvalsh((P + P.T) / 2).min() > 0                # and positive definite
+        err = np.hypot(poses[b, -2000:, 0] - tr.truth[b, -2000:, 0], poses[b, -2000:, 1] - tr.truth[b, -2000:, 1])
+        assert err.max() < 0.2                                            # the filter tracks the ground truth
+        assert len(core.wait_list(b)[0]) == L
+    # one 5000-callback launch vs 5 x 1000: identical bits (state round-trips through HBM between launches)
+    sub = tg.Trace(tr.odom[:2, :5000], tr.dt[:2, :5000], tr.obs_new[:2, :5000], tr.n_obs[:2, :5000], tr.obs[:2, :5000],
+                   tr.landmarks[:2], tr.truth[:2, :5000])
+    c1, p1, _ = gpu_replay("ekf", sub, tg.dim_cap(L))
+    c2, p2, _ = gpu_replay("ekf", sub, tg.dim_cap(L), chunk=1000)
+    assert np.array_equal(p1, p2) and np.array_equal(c1.state(1)[2], c2.state(1)[2])
