@@ -72,6 +72,10 @@ def core_lib():
         if not os.path.exists(_CORE):
             raise OSError(f"{_CORE} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the filter core)")
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's libamdhip64.so.7): it has to be in
+        # the process first so that libaslam_core.so binds to that one copy instead of loading a second runtime
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(_CORE)
         vp, ci, cf, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
         pd, pf, pi, pu = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_float, ctypes.c_int, ctypes.c_uint32))

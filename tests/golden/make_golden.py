@@ -23,7 +23,7 @@ from oracle.np_oracle import NpFilter  # noqa: E402
 CASES = {
     "ekf_L5": ("ekf", 5, 400, dict(seed=101), 30),        # BASELINE config 1 as named (5 landmarks), shipped cap 30
     "ekf_L8": ("ekf", 8, 400, dict(seed=102), 30),        # config 1 as shipped (landmarks.yaml has 8), cap 30
-    "ekf_L13_cap": ("ekf", 14, 300, dict(seed=103, stages=2), 30),  # 14 landmarks against the shipped cap: last growth refused
+    "ekf_L13_cap": ("ekf", 14, 100, dict(seed=103, stages=2), 30),  # 14 landmarks against the shipped cap: last growth refused
     "ekf_L8_rewalk": ("ekf", 8, 300, dict(seed=104, sensor_every=3, dt_mode="random"), 30),
     "ekf_L8_junk": ("ekf", 8, 300, dict(seed=105, warm_hop=12, layout="ring", sensor_range=6.0), 30),
     "ukf_L5": ("ukf", 5, 300, dict(seed=111), 30),
