@@ -50,6 +50,9 @@ struct aslam_ctx
         int64_t hbm_bytes;
         size_t lds_bytes;
         std::string kernel_name;
+#if ASLAM_HAVE_UKF
+        UkfView ukf;
+#endif
 };
 
 namespace
@@ -123,6 +126,22 @@ int launch_ekf(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, in
 }
 
 #if ASLAM_HAVE_UKF
+/// HBM scratch of the UKF kernels: D, DZ ([NP][MP]) and Tc, K ([NP][NP]) per filter
+int ukf_alloc(aslam_ctx *c)
+{
+        const size_t B = (size_t)c->cfg.batch, NP = (size_t)c->NP;
+        const size_t MP = 2 * NP + 16;
+        c->ukf.MP = (int)MP;
+        int rc = dev_alloc(c, &c->ukf.D, B * NP * MP, c->owned);
+        if (rc == ASLAM_OK)
+                rc = dev_alloc(c, &c->ukf.DZ, B * NP * MP, c->owned);
+        if (rc == ASLAM_OK)
+                rc = dev_alloc(c, &c->ukf.Tc, B * NP * NP, c->owned);
+        if (rc == ASLAM_OK)
+                rc = dev_alloc(c, &c->ukf.K, B * NP * NP, c->owned);
+        return rc;
+}
+
 template <int NT, int MODE>
 int launch_ukf(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa, hipStream_t st)
 {
@@ -150,6 +169,20 @@ int launch(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_
                         return launch_ekf<9, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
                 }
         }
+#if ASLAM_HAVE_UKF
+        if (c->cfg.filter == ASLAM_UKF)
+        {
+                switch (c->NT)
+                {
+                case 2:
+                        return launch_ukf<2, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                case 5:
+                        return launch_ukf<5, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                case 9:
+                        return launch_ukf<9, MODE>(c, grid, t0, nsteps, poses, dims, sa, st);
+                }
+        }
+#endif
         return fail(ASLAM_ERR_UNSUPPORTED, "no kernel for this filter/size");
 }
 } // namespace
@@ -227,6 +260,9 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         A_(dev_alloc(c, &d.wait_rb, B * cfg->max_wait * 2, c->owned));
         A_(dev_alloc(c, &d.wait_cnt, B * cfg->max_wait, c->owned));
         A_(dev_alloc(c, &d.wait_n, B, c->owned));
+#ifdef ASLAM_STAMPS
+        A_(dev_alloc(c, &d.dbg, 16, c->owned));
+#endif
 #if ASLAM_HAVE_UKF
         if (rc == ASLAM_OK && cfg->filter == ASLAM_UKF)
                 rc = ukf_alloc(c);
@@ -602,6 +638,34 @@ int aslam_get_layout(aslam_ctx *c, int *padded_dim, int64_t *hbm_bytes)
                 *hbm_bytes = c->hbm_bytes;
         return ASLAM_OK;
 }
+
+#if defined(ASLAM_STAMPS) && ASLAM_HAVE_UKF
+/* diagnostic builds only: copy a UKF scratch matrix of filter `traj` to the host. which: 0 D, 1 DZ ([NP][MP]), 2 Tc, 3 K ([NP][NP]) */
+int aslam_debug_ukf(aslam_ctx *c, int traj, int which, double *out, int *rows, int *cols)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        const size_t NP = c->NP, MP = c->ukf.MP;
+        const double *src = which == 0 ? c->ukf.D + traj * NP * MP : which == 1 ? c->ukf.DZ + traj * NP * MP
+                            : which == 2 ? c->ukf.Tc + traj * NP * NP : c->ukf.K + traj * NP * NP;
+        const size_t cnt = which < 2 ? NP * MP : NP * NP;
+        *rows = (int)NP;
+        *cols = which < 2 ? (int)MP : (int)NP;
+        HIP_TRY(hipMemcpy(out, src, cnt * sizeof(double), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+#endif
+
+#ifdef ASLAM_STAMPS
+/* diagnostic builds only: per-phase shader-cycle sums of workgroup 0 since the context was created */
+int aslam_debug_stamps(aslam_ctx *c, unsigned long long *out12)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        HIP_TRY(hipMemcpy(out12, c->dv.dbg, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+#endif
 
 int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *block, int *lds_bytes)
 {

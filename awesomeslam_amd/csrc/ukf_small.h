@@ -1,0 +1,547 @@
+// ukf_small.h -- fused per-trajectory UKF-SLAM kernel for state dimensions that fit one CU (n <= 16*NT <= 144).
+//
+// One 1024-thread workgroup owns one filter and runs whole callbacks of the reference's UKF node:
+//     cbSensorLandmark ukf.cpp:98-110 -> updateZ ukf.cpp:113-180 (+ wait-list, growth ukf.cpp:184-257) -> slam ukf.cpp:260-392
+// (the front end is shared with the EKF: small_common.h).
+//
+// slam() follows ukf.cpp line by line, with the 2N+5 sigma points kept implicit where they are affine:
+//   * L = chol(P) by the LDS tile Cholesky (the two augmentation dimensions of Paug are diagonal, ukf.cpp:271-277);
+//     a sigma point's landmark entries are X +- w L(:,c) (ukf.cpp:283-289) and pass through f unchanged
+//     (common.h:49-50), so only the three pose entries of every sigma point are pushed through f (ukf.cpp:292-297);
+//   * the difference matrices D (state, ukf.cpp:311-312) and DZ (measurement, ukf.cpp:346-351) are materialised once
+//     in HBM/L2, row-major [n][2N+5 padded to 16];
+//   * the three weighted outer-product sums P = sum w d d^T (ukf.cpp:307-319), S = sum w dz dz^T (ukf.cpp:342-357),
+//     Tc = sum w d dz^T (ukf.cpp:360-375) are GEMMs A diag(w) B^T on the f64 MFMA, operand slabs staged through LDS
+//     (double-buffered, register prefetch);
+//   * K = Tc S^-1 (ukf.cpp:378): the central weight (1-N)/3 is negative, so S may be indefinite; its positive part
+//     S+ goes through the tile Cholesky and the row-block MFMA solves shared with the EKF, the rank-1 rest through
+//     Sherman-Morrison (exact); K S K^T is evaluated as Tc K^T (K S = Tc), one more GEMM (ukf.cpp:391).
+// Every binary32 rounding point of the reference is kept: fp32 lambda / weights / sqrt(lambda+N+2) (ukf.h:73-81,
+// ukf.cpp:284), fp32 noise variances (ukf.cpp:276-277), normalizeAngle on sigma-point headings, on the heading
+// row of D and on the bearing rows of Zpred, DZ and the innovation.
+#pragma once
+
+#include "small_common.h"
+
+namespace aslam
+{
+/// HBM scratch of the UKF kernels (per context)
+struct UkfView
+{
+        int MP;     // padded sigma-point count (row stride of D / DZ), multiple of 16
+        double *D;  // [B][NP][MP]  XsigPred - X (state differences)
+        double *DZ; // [B][NP][MP]  Zsig, then Zsig - Zpred
+        double *Tc; // [B][NP][NP]
+        double *K;  // [B][NP][NP]
+};
+
+template <int NT> struct UkfLayout
+{
+        typedef SmallLayout<NT> LY;
+        static constexpr int NP = LY::NP;
+        static constexpr int MP = 2 * NP + 16; // >= 2 n + 5 rounded up to 16 for every n <= NP - 1
+        static constexpr size_t oXP = (LY::total + 15) & ~(size_t)15; // double[3][MP] propagated sigma-point poses
+        static constexpr size_t oW = oXP + 8 * 3 * MP;                 // double[MP] weights
+        static constexpr size_t oXbar = oW + 8 * MP;                   // double[NP] predicted mean
+        static constexpr size_t oZpred = oXbar + 8 * NP;               // double[NP]
+        // GEMM staging: 2 buffers x (A, B) slabs.  Where it fits it overlays the tile region (the Cholesky factor of
+        // P is dead by then, and at NT = 9 there is no room for both); smaller NT get an area of their own.
+        static constexpr int SLAB_LD = 17;                  // doubles per slab row (16 + 1 pad: conflict-free MFMA operand reads)
+        static constexpr int SLAB = NP * SLAB_LD;           // doubles per slab
+        static constexpr bool STAGE_OVERLAYS_TILES = (4 * SLAB <= LY::NTILES * 256);
+        static constexpr size_t oZv = oZpred + 8 * NP;                 // double[NP] z = sqrt(-w0) dz_0 (rank-1 part of S)
+        static constexpr size_t oVv = oZv + 8 * NP;                    // double[NP] v = S+^-1 z
+        static constexpr size_t oGv = oVv + 8 * NP;                    // double[NP] g = K+ z
+        static constexpr size_t oStage = oGv + 8 * NP;
+        static constexpr size_t total = oStage + (STAGE_OVERLAYS_TILES ? 0 : 8 * 4 * SLAB);
+};
+
+enum
+{
+        GEMM_STORE = 0,    // C = A diag(w) B^T            (HBM, full matrix)
+        GEMM_SUBTRACT = 1, // C -= A diag(w) B^T           (HBM, full matrix)
+        GEMM_TILES = 2     // lower tiles of A diag(w) B^T + diag_add on the true diagonal -> LDS tile storage
+};
+
+/// C (op)= A diag(w) B^T over k = 0 .. 16*nks-1 (SKIP_K0: without the k = 0 term).  A, B: row-major HBM with row stride ld (>= 16*nks), rows
+/// [0, 16*nt).  w: LDS weights or nullptr.  All 1024 threads of the workgroup take part; `stage` is 4*SLAB doubles
+/// of LDS.  Output tiles are dealt round-robin to the 16 waves (<= TPW per wave).
+template <int NT, int MODE, bool SKIP_K0 = false>
+__device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int ld, int nks, const double *w, int nt,
+                                          double *Cg, double *Ct, double diag_add, int n_true, double *stage, int tid)
+{
+        typedef UkfLayout<NT> UL;
+        constexpr int NP = UL::NP, LD = UL::SLAB_LD, SLAB = UL::SLAB;
+        constexpr int TPW = (MODE == GEMM_TILES) ? (NT * (NT + 1) / 2 + SMALL_WAVES - 1) / SMALL_WAVES
+                                                 : (NT * NT + SMALL_WAVES - 1) / SMALL_WAVES;
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const bool same = (A == B);
+        const int rows = 16 * nt;
+        const int ntiles = (MODE == GEMM_TILES) ? nt * (nt + 1) / 2 : nt * nt;
+
+        // my output tiles
+        int tib[TPW], tjb[TPW];
+        d4 acc[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+        {
+                const int tl = wave + q * SMALL_WAVES;
+                int ib = 0, jb = 0;
+                if (tl < ntiles)
+                {
+                        if (MODE == GEMM_TILES)
+                        {
+                                ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+                                while ((ib + 1) * (ib + 2) / 2 <= tl)
+                                        ++ib;
+                                while (ib * (ib + 1) / 2 > tl)
+                                        --ib;
+                                jb = tl - ib * (ib + 1) / 2;
+                        }
+                        else
+                        {
+                                ib = tl / nt;
+                                jb = tl - ib * nt;
+                        }
+                }
+                tib[q] = ib;
+                tjb[q] = jb;
+                acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+
+        // slab loader: element pairs (row, 2 consecutive k) -> one 16-byte load per pair
+        const int npairs = rows * 8;
+        double2 ra[2], rbv[2];
+        auto fetch = [&](int ks) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                        const int pi = tid + u * SMALL_WG;
+                        if (pi < npairs)
+                        {
+                                const int r = pi >> 3, c2 = (pi & 7) * 2;
+                                ra[u] = *reinterpret_cast<const double2 *>(A + (size_t)r * ld + 16 * ks + c2);
+                                if (!same)
+                                        rbv[u] = *reinterpret_cast<const double2 *>(B + (size_t)r * ld + 16 * ks + c2);
+                        }
+                }
+        };
+        auto stash = [&](int buf) {
+                double *sa_ = stage + (size_t)buf * 2 * SLAB, *sb_ = sa_ + SLAB;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                        const int pi = tid + u * SMALL_WG;
+                        if (pi < npairs)
+                        {
+                                const int r = pi >> 3, c2 = (pi & 7) * 2;
+                                sa_[r * LD + c2] = ra[u].x;
+                                sa_[r * LD + c2 + 1] = ra[u].y;
+                                if (!same)
+                                {
+                                        sb_[r * LD + c2] = rbv[u].x;
+                                        sb_[r * LD + c2 + 1] = rbv[u].y;
+                                }
+                        }
+                }
+        };
+
+        __syncthreads(); // whatever lived in the staging region before is dead from here on
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int ks = 0; ks < nks; ++ks)
+        {
+                const int buf = ks & 1;
+                if (ks + 1 < nks)
+                        fetch(ks + 1);
+                const double *sa_ = stage + (size_t)buf * 2 * SLAB;
+                const double *sb_ = same ? sa_ : sa_ + SLAB;
+                double wv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                        const int kk = 16 * ks + lg + 4 * s;
+                        wv[s] = (SKIP_K0 && kk == 0) ? 0.0 : (w ? w[kk] : 1.0);
+                }
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                {
+                        if (wave + q * SMALL_WAVES < ntiles)
+                        {
+                                const double *ar = sa_ + (16 * tib[q] + li) * LD + lg;
+                                const double *br = sb_ + (16 * tjb[q] + li) * LD + lg;
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                        acc[q] = mfma_f64(wv[s] * ar[4 * s], br[4 * s], acc[q]); // (w d_a) d_b, ukf.cpp:315
+                        }
+                }
+                if (ks + 1 < nks)
+                        stash(buf ^ 1);
+                __syncthreads();
+        }
+
+        // write out: lane l, register r of a tile = element (row (l>>4) + 4 r, column l&15)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+        {
+                if (wave + q * SMALL_WAVES < ntiles)
+                {
+                        const int ib = tib[q], jb = tjb[q];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                const int i = 16 * ib + lg + 4 * r, j = 16 * jb + li;
+                                if (MODE == GEMM_TILES)
+                                {
+                                        double v = acc[q][r];
+                                        if (i == j)
+                                                v += (i < n_true) ? diag_add : 1.0;
+                                        Ct[tile_index(ib, jb) * 256 + (lg + 4 * r) * 16 + li] = v;
+                                }
+                                else if (MODE == GEMM_STORE)
+                                        Cg[(size_t)i * NP + j] = acc[q][r];
+                                else
+                                        Cg[(size_t)i * NP + j] -= acc[q][r];
+                        }
+                }
+        }
+        __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int NT, int MODE>
+__global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView uv, int64_t t0, int nsteps, double *poses_out,
+                                                              int32_t *dims_out, StepArgs sa)
+{
+        typedef SmallLayout<NT> LY;
+        typedef UkfLayout<NT> UL;
+        constexpr int NP = LY::NP;
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+        const SmallLds L = small_carve<NT>(smem);
+        double *const Lt = L.Lt, *const Dinv = L.Dinv, *const sX = L.sX, *const sZ = L.sZ, *const sY = L.sY, *const sU = L.sU;
+        double *const sXP = reinterpret_cast<double *>(smem + UL::oXP);
+        double *const sW = reinterpret_cast<double *>(smem + UL::oW);
+        double *const sXbar = reinterpret_cast<double *>(smem + UL::oXbar);
+        double *const sZpred = reinterpret_cast<double *>(smem + UL::oZpred);
+        double *const sZv = reinterpret_cast<double *>(smem + UL::oZv);
+        double *const sVv = reinterpret_cast<double *>(smem + UL::oVv);
+        double *const sGv = reinterpret_cast<double *>(smem + UL::oGv);
+        double *const stage = UL::STAGE_OVERLAYS_TILES ? Lt : reinterpret_cast<double *>(smem + UL::oStage);
+        SmallShared &sm = *L.sm;
+
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
+        const int MP = uv.MP;
+        double *Pg = d.P + (size_t)b * NP * NP;
+        double *Dg = uv.D + (size_t)b * NP * MP;
+        double *DZg = uv.DZ + (size_t)b * NP * MP;
+        double *Tcg = uv.Tc + (size_t)b * NP * NP;
+        double *Kg = uv.K + (size_t)b * NP * NP;
+        const double r_meas = (double)KR, q_proc = (double)KQ;
+
+        small_load<NP, MODE>(d, L, b, tid);
+
+        for (int s = 0; s < nsteps; ++s)
+        {
+                const int64_t t = t0 + s;
+                if (MODE == MODE_REPLAY)
+                {
+                        if (small_frontend<NP, false>(d, L, Pg, b, t, s, nsteps, poses_out, dims_out, tid))
+                                continue;
+                }
+                else
+                {
+                        if (tid == 0)
+                        {
+                                sm.vx = sa.vx;
+                                sm.az = sa.az;
+                                sm.dt = sa.dt;
+                        }
+                        __syncthreads();
+                }
+
+                // ================= slam(), ukf.cpp:260-392
+                const int n = sm.n;
+                const int nl = (n - 3) / 2;
+                const int nt = (n + 15) >> 4;
+                const int m = 2 * n + 5;
+                const int mt = (m + 15) >> 4;
+                const float vx = sm.vx, az = sm.az, dtf = sm.dt;
+                // updateWeights, ukf.h:73-81 (binary32 lambda, weight) and w = sqrt(lambda + N + 2), ukf.cpp:284
+                const float lambda_f = (float)(3.0 - (double)(n + 2));
+                const float den_f = (lambda_f + (float)n) + 2.0f;
+                const double w_i = (double)(float)(0.5 / (double)den_f);
+                const double w_0 = (double)(lambda_f / den_f);
+                const double wsp = (double)sqrtf(den_f);
+                const double std_a = sqrt((double)(UKF_STD_A * UKF_STD_A)); // llt of the augmented diagonal, ukf.cpp:276,280
+                for (int i = tid; i < 16 * mt; i += SMALL_WG)
+                        sW[i] = (i < m) ? (i == 0 ? w_0 : w_i) : 0.0;
+
+                // ---- L = Paug.llt().matrixL(), ukf.cpp:280: lower tiles of P -> LDS -> tile Cholesky
+                {
+                        const int ntl = nt * (nt + 1) / 2;
+                        for (int idx = tid; idx < ntl * 256; idx += SMALL_WG)
+                        {
+                                const int tl = idx >> 8, e = idx & 255;
+                                int ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+                                while ((ib + 1) * (ib + 2) / 2 <= tl)
+                                        ++ib;
+                                while (ib * (ib + 1) / 2 > tl)
+                                        --ib;
+                                const int jb = tl - ib * (ib + 1) / 2;
+                                const int i = 16 * ib + (e >> 4), j = 16 * jb + (e & 15);
+                                double v = Pg[(size_t)i * NP + j];
+                                if (i == j && i >= n)
+                                        v = 1.0;
+                                Lt[idx] = v;
+                        }
+                }
+                __syncthreads();
+                cholesky_tiles<NT>(Lt, Dinv, nt, tid, &sm.status);
+
+                // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)
+                auto Lkc = [&](int k, int c) -> double {
+                        return (c <= k) ? Lt[tile_index(k >> 4, c >> 4) * 256 + (k & 15) * 16 + (c & 15)] : 0.0;
+                };
+                // sigma point i -> (column c of Laug, sign); i = 0 is the mean itself
+                auto col_of = [&](int i, int &c, double &sg) {
+                        if (i == 0)
+                        {
+                                c = -1;
+                                sg = 0.0;
+                        }
+                        else if (i <= n + 2)
+                        {
+                                c = i - 1;
+                                sg = 1.0;
+                        }
+                        else
+                        {
+                                c = i - n - 3;
+                                sg = -1.0;
+                        }
+                };
+                // entry k < n of augmented sigma point i: Xaug(k) +- w * L(k, c)  (ukf.cpp:287-288)
+                auto xsig = [&](int k, int c, double sg) -> double {
+                        if (c < 0)
+                                return sX[k];
+                        const double l = (c < n) ? Lkc(k, c) : 0.0;
+                        return sg > 0.0 ? sX[k] + wsp * l : sX[k] - wsp * l;
+                };
+
+                // ---- propagate the pose of every sigma point, ukf.cpp:292-297
+                for (int i = tid; i < 16 * mt; i += SMALL_WG)
+                {
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+                        if (i < m)
+                        {
+                                int c;
+                                double sg;
+                                col_of(i, c, sg);
+                                p0 = xsig(0, c, sg);
+                                p1 = xsig(1, c, sg);
+                                p2 = xsig(2, c, sg);
+                                // XsigAug(N, i): 0 +- w * Laug(N, N) on the acceleration-noise column, 0 elsewhere
+                                double na = 0.0;
+                                if (c == n)
+                                        na = sg > 0.0 ? 0.0 + wsp * std_a : 0.0 - wsp * std_a;
+                                stateTransition(p0, p1, p2, vx, az, dtf, true, na);
+                                p2 = (double)normalizeAngle((float)p2);
+                        }
+                        sXP[i] = p0;
+                        sXP[UL::MP + i] = p1;
+                        sXP[2 * UL::MP + i] = p2;
+                }
+                __syncthreads();
+
+                // ---- predicted mean, ukf.cpp:300-304 (same term order as the reference's loop over i)
+                for (int k = tid; k < NP; k += SMALL_WG)
+                {
+                        double acc = 0.0;
+                        if (k < 3)
+                        {
+                                for (int i = 0; i < m; ++i)
+                                        acc += sW[i] * sXP[k * UL::MP + i];
+                        }
+                        else if (k < n)
+                        {
+                                acc += w_0 * sX[k];
+                                for (int c = 0; c < n + 2; ++c)
+                                        acc += w_i * (sX[k] + wsp * ((c < n) ? Lkc(k, c) : 0.0));
+                                for (int c = 0; c < n + 2; ++c)
+                                        acc += w_i * (sX[k] - wsp * ((c < n) ? Lkc(k, c) : 0.0));
+                        }
+                        sXbar[k] = acc;
+                }
+                __syncthreads();
+
+                // ---- D = XsigPred - X, heading row wrapped (ukf.cpp:311-312), zero padding
+                for (int idx = tid; idx < 16 * nt * 16 * mt; idx += SMALL_WG)
+                {
+                        const int k = idx / (16 * mt), i = idx - k * (16 * mt);
+                        double v = 0.0;
+                        if (k < n && i < m)
+                        {
+                                if (k < 3)
+                                {
+                                        v = sXP[k * UL::MP + i] - sXbar[k];
+                                        if (k == 2)
+                                                v = (double)normalizeAngle((float)v);
+                                }
+                                else
+                                {
+                                        int c;
+                                        double sg;
+                                        col_of(i, c, sg);
+                                        v = xsig(k, c, sg) - sXbar[k];
+                                }
+                        }
+                        Dg[(size_t)k * MP + i] = v;
+                }
+                // ---- Zsig = h(XsigPred), ukf.cpp:322-326 / common.h:78-90: pose rows pass through
+                for (int idx = tid; idx < 3 * 16 * mt; idx += SMALL_WG)
+                {
+                        const int k = idx / (16 * mt), i = idx - k * (16 * mt);
+                        DZg[(size_t)k * MP + i] = (i < m) ? sXP[k * UL::MP + i] : 0.0;
+                }
+                for (int idx = tid; idx < nl * 16 * mt; idx += SMALL_WG)
+                {
+                        const int j = idx / (16 * mt), i = idx - j * (16 * mt);
+                        double zr = 0.0, zb = 0.0;
+                        if (i < m)
+                        {
+                                int c;
+                                double sg;
+                                col_of(i, c, sg);
+                                const double lx = xsig(3 + 2 * j, c, sg), ly = xsig(4 + 2 * j, c, sg);
+                                const double ddx = lx - sXP[i], ddy = ly - sXP[UL::MP + i];
+                                zr = sqrt(ddx * ddx + ddy * ddy);
+                                zb = atan2(ddy, ddx) - sXP[2 * UL::MP + i];
+                        }
+                        DZg[(size_t)(3 + 2 * j) * MP + i] = zr;
+                        DZg[(size_t)(4 + 2 * j) * MP + i] = zb;
+                }
+                for (int idx = tid; idx < (16 * nt - n) * 16 * mt; idx += SMALL_WG)
+                {
+                        const int k = n + idx / (16 * mt), i = idx % (16 * mt);
+                        DZg[(size_t)k * MP + i] = 0.0;
+                }
+                __syncthreads();
+
+                // ---- P = sum w d d^T + Q, ukf.cpp:307-319 (tile region of LDS becomes GEMM staging: L is dead)
+                gemm_wabt<NT, GEMM_STORE>(Dg, Dg, MP, mt, sW, nt, Pg, nullptr, 0.0, n, stage, tid);
+                if (tid < 3)
+                        Pg[(size_t)tid * NP + tid] += q_proc;
+
+                // ---- Zpred = sum w Zsig, bearings wrapped (ukf.cpp:329-339); innovation Zdiff (ukf.cpp:381-386)
+                for (int k = tid; k < NP; k += SMALL_WG)
+                {
+                        double acc = 0.0;
+                        if (k < n)
+                        {
+                                const double *row = DZg + (size_t)k * MP;
+                                for (int i = 0; i < m; ++i)
+                                        acc += sW[i] * row[i];
+                                const bool wrapped = (k >= 2) && ((k & 1) == 0); // entries 2, 4, ..., N-1
+                                if (wrapped)
+                                        acc = (double)normalizeAngle((float)acc);
+                                double zd = sZ[k] - acc;
+                                if (wrapped)
+                                        zd = (double)normalizeAngle((float)zd);
+                                sY[k] = zd;
+                        }
+                        else
+                                sY[k] = 0.0;
+                        sZpred[k] = acc;
+                }
+                __syncthreads();
+                // ---- DZ = Zsig - Zpred, bearings wrapped (ukf.cpp:346-351), in place
+                for (int idx = tid; idx < n * m; idx += SMALL_WG)
+                {
+                        const int k = idx / m, i = idx - k * m;
+                        double v = DZg[(size_t)k * MP + i] - sZpred[k];
+                        if ((k >= 2) && ((k & 1) == 0))
+                                v = (double)normalizeAngle((float)v);
+                        DZg[(size_t)k * MP + i] = v;
+                }
+                __syncthreads();
+
+                // ---- Tc = sum w d dz^T (ukf.cpp:360-375) -> HBM
+                gemm_wabt<NT, GEMM_STORE>(Dg, DZg, MP, mt, sW, nt, Tcg, nullptr, 0.0, n, stage, tid);
+                // ---- S = sum w dz dz^T + R (ukf.cpp:342-357).  The central weight w_0 = (1-N)/3 is negative, so S can be
+                // indefinite (it is whenever the sigma-point headings straddle +-pi); the reference does not care because it
+                // inverts S by LU (S.inverse(), ukf.cpp:378).  Here: S = S+ - z z^T with S+ = sum_{i>=1} w_i dz_i dz_i^T + R
+                // (symmetric positive definite -> LDS tiles -> tile Cholesky) and z = sqrt(-w_0) dz_0, and
+                //     Tc S^-1 = K+ + (K+ z) v^T / (1 - z^T v),   K+ = Tc S+^-1,  v = S+^-1 z      (Sherman-Morrison, exact).
+                const double zscale = sqrt(-w_0);
+                for (int k = tid; k < NP; k += SMALL_WG)
+                        sZv[k] = (k < n) ? zscale * DZg[(size_t)k * MP] : 0.0;
+                gemm_wabt<NT, GEMM_TILES, true>(DZg, DZg, MP, mt, sW, nt, nullptr, Lt, r_meas, n, stage, tid);
+                // (GEMM_TILES wrote the tiles over the staging area after its last barrier; it ends with a barrier)
+                // z rides along as right-hand side row n (n is odd, so row n is always a padding row of the last tile)
+                for (int j = tid; j < 16 * nt; j += SMALL_WG)
+                        Tcg[(size_t)n * NP + j] = sZv[j];
+                cholesky_tiles<NT>(Lt, Dinv, nt, tid, &sm.status);
+                // ---- K+ = Tc S+^-1 (and v^T = z^T S+^-1 in row n), u+ = K+ Zdiff
+                if (wave < nt)
+                        solve_row_block<NT>(Tcg, Kg, wave, nt, Lt, Dinv, sY, sU, 1.0, lane);
+                __syncthreads();
+                for (int j = tid; j < NP; j += SMALL_WG)
+                        sVv[j] = (j < 16 * nt) ? Kg[(size_t)n * NP + j] : 0.0;
+                for (int a = tid; a < NP; a += SMALL_WG)
+                {
+                        double g = 0.0;
+                        if (a < n)
+                        {
+                                const double *row = Kg + (size_t)a * NP;
+                                for (int j = 0; j < n; ++j)
+                                        g = fma(row[j], sZv[j], g);
+                        }
+                        sGv[a] = g;
+                }
+                __syncthreads();
+                {
+                        // the padding row goes back to zero before anything else reads Tc / K
+                        for (int j = tid; j < 16 * nt; j += SMALL_WG)
+                        {
+                                Tcg[(size_t)n * NP + j] = 0.0;
+                                Kg[(size_t)n * NP + j] = 0.0;
+                        }
+                        double zv = 0.0, vy = 0.0;
+                        for (int j = 0; j < n; ++j)
+                        {
+                                zv = fma(sZv[j], sVv[j], zv);
+                                vy = fma(sVv[j], sY[j], vy);
+                        }
+                        const double inv_den = 1.0 / (1.0 - zv);
+                        // K = K+ + g v^T / (1 - z^T v)  (ukf.cpp:378), u = K Zdiff
+                        for (int idx = tid; idx < n * n; idx += SMALL_WG)
+                        {
+                                const int a = idx / n, j = idx - a * n;
+                                Kg[(size_t)a * NP + j] += sGv[a] * inv_den * sVv[j];
+                        }
+                        __syncthreads();
+                        for (int a = tid; a < n; a += SMALL_WG)
+                                sU[a] += sGv[a] * inv_den * vy;
+                }
+                __syncthreads();
+                // ---- X = X + K Zdiff (ukf.cpp:389)
+                for (int k = tid; k < n; k += SMALL_WG)
+                        sX[k] = sXbar[k] + sU[k];
+                // ---- P = P - K S K^T (ukf.cpp:391): K S = Tc, so (K S) K^T = Tc K^T
+                gemm_wabt<NT, GEMM_SUBTRACT>(Tcg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid);
+
+                if (MODE == MODE_REPLAY)
+                {
+                        if (tid < 3 && poses_out)
+                                poses_out[((size_t)b * nsteps + s) * 3 + tid] = sX[tid];
+                        if (tid == 0 && dims_out)
+                                dims_out[(size_t)b * nsteps + s] = n;
+                }
+                __syncthreads();
+        }
+
+        small_store<NP, MODE>(d, L, b, tid);
+}
+} // namespace aslam

@@ -65,7 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ekf64", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="trajectories per GPU")
-    ap.add_argument("--chunk", type=int, default=500, help="callbacks per launch (= per bench step)")
+    ap.add_argument("--chunk", type=int, default=None,
+                    help="callbacks per launch (= per bench step); default 500 (EKF) / 200 (UKF: the reference UKF only stays "
+                         "positive definite for a few thousand callbacks at n = 131, DESIGN.md)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=None, help="callbacks timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -80,6 +82,8 @@ def main():
 
     kind, L, cfg_name = WORKLOADS[args.workload]
     n_full = tg.full_dim(L)
+    if args.chunk is None:
+        args.chunk = 200 if kind == "ukf" else 500
     B, C, K, W = args.batch, args.chunk, args.steps, args.warmup
     prologue = 64  # callbacks: the 42-callback warm-up in which the state grows to n_full, rounded up
     T = prologue + (W + K) * C

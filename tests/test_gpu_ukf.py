@@ -1,0 +1,132 @@
+"""-m gpu: the HIP UKF path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Same bars as the EKF: 1e-6 relative on state/covariance, bit-exact landmark bookkeeping.  The scenario keeps
+the reference UKF positive definite (its central weight is negative: (1-N)/3, ukf.h:75-80); every test asserts
+that on the oracle instead of comparing NaNs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from awesomeslam_amd import trace as tg
+from test_gpu_ekf import assert_parity, gpu_replay
+from util import REL_TOL, rel_err, sub_trajectory
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("L5", 5, 600, dict(seed=41), 30, None),
+    ("L8", 8, 600, dict(seed=42), 30, 97),
+    ("L13-4stages", 13, 300, dict(seed=43, stages=4), 30, None),
+    ("L8-rewalk-randomdt", 8, 300, dict(seed=44, sensor_every=2, dt_mode="random"), 30, 50),
+    ("L20", 20, 200, dict(seed=45), None, None),       # NT = 5 kernel
+    ("L64", 64, 250, dict(seed=46), None, 100),        # BASELINE config 3 geometry (n = 131, 267 sigma points)
+]
+
+
+@pytest.mark.parametrize("name,L,T,kw,cap,chunk", CASES, ids=[c[0] for c in CASES])
+def test_replay_parity(name, L, T, kw, cap, chunk, built):
+    from oracle.c_oracle import CFilter
+
+    cap = tg.dim_cap(L) if cap is None else cap
+    B = 2
+    tr = tg.make_traces(L, T, B=B, **kw)
+    core, poses, dims = gpu_replay("ukf", tr, cap, chunk)
+    for b in range(B):
+        o = CFilter("ukf", cap)
+        po, do = o.replay(tr[b])
+        Po = o.state()[2]
+        assert np.isfinite(Po).all() and np.linalg.eigvalsh((Po + Po.T) / 2).min() > 0, "scenario must keep the oracle PD"
+        errs = assert_parity(core, b, poses[b], dims[b], o, po, do)
+        print(f"ukf {name} b={b} N={core.dim(b)} rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        assert core.status(b) == 0
+
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ukf_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_golden(path, built):
+    z = np.load(path)
+    tr = tg.Trace(z["odom"][None], z["dt"][None], z["obs_new"][None], z["n_obs"][None], z["obs"][None],
+                  np.zeros((1, 1, 2)), np.zeros((1, z["odom"].shape[0], 3)))
+    core, poses, dims = gpu_replay("ukf", tr, int(z["cap"]))
+    X, Z, P = core.state(0)
+    assert np.array_equal(dims[0], z["dims"]) and np.array_equal(Z, z["Z"])
+    w = core.wait_list(0)
+    assert np.array_equal(w[0], z["wait_range"]) and np.array_equal(w[1], z["wait_bearing"]) and np.array_equal(w[2], z["wait_count"])
+    assert max(rel_err(poses[0], z["poses"]), rel_err(X, z["X"]), rel_err(P, z["P"])) < REL_TOL
+
+
+@pytest.mark.parametrize("L,T,kw", [(5, 120, dict(seed=51)), (8, 150, dict(seed=52, sensor_every=2))])
+def test_per_callback_seam_host_mirror(L, T, kw, built):
+    """aslam::UKFSlam host mirror (C++): association/growth on the host, P/X/slam() on the GPU."""
+    from awesomeslam_amd.core import Node
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(L, T, B=1, **kw)[0]
+    node = Node("ukf", 30)
+    pn, dn = node.replay(tr)
+    o = CFilter("ukf", 30)
+    po, do = o.replay(tr)
+    Xo, Zo, Po = o.state()
+    X, Z, _, _ = node.state()
+    assert np.array_equal(dn, do) and np.array_equal(Z, Zo)
+    assert max(rel_err(pn, po), rel_err(X, Xo), rel_err(node.P(), Po)) < REL_TOL
+
+
+@pytest.mark.parametrize("n", [3, 13, 29, 61, 131])
+def test_single_slam_on_synthetic_state(n, built):
+    from awesomeslam_amd.core import Core
+    from oracle.c_oracle import CFilter
+
+    rng = np.random.default_rng(100 + n)
+    L = (n - 3) // 2
+    X = np.concatenate([[0.3, -0.2, 0.4], (np.array([25.0, 0.0]) + 4 * rng.normal(size=(L, 2))).ravel()])
+    A = rng.normal(size=(n, n)) * 0.01
+    P = A @ A.T + np.eye(n) * 0.002
+    Z = X.copy()
+    for i in range(L):
+        dx, dy = X[3 + 2 * i] - X[0], X[4 + 2 * i] - X[1]
+        Z[3 + 2 * i] = np.float32(np.hypot(dx, dy) + 0.01 * rng.normal())
+        Z[4 + 2 * i] = np.float32(np.arctan2(dy, dx) - X[2] + 0.002 * rng.normal())
+    cap = max(30, n + 1)
+    core = Core("ukf", cap, batch=2, max_obs=4, max_wait=4)
+    o = CFilter("ukf", cap)
+    core.set_state(0, n, X, Z, P)
+    o.set_state(n, X, Z, P)
+    for vx, az, dt in ((0.2, 0.1, 1.0), (0.15, 0.0, 0.5), (0.0, 0.0, 1.0)):
+        Xg = core.ukf_step(0, vx, az, dt, Z)
+        o.slam(vx, az, dt)
+        Xo, _, Po = o.state()
+        assert np.isfinite(Po).all()
+        assert rel_err(Xg, Xo) < REL_TOL
+    assert rel_err(core.state(0)[2], Po) < REL_TOL
+    assert core.status(0) == 0
+
+
+def test_full_size_config3_properties(built):
+    """BASELINE config 3 geometry (64 landmarks, n = 131, 267 sigma points) over the window in which the REFERENCE
+    filter is still healthy: with w_0 = (1-N)/3 = -43.3 the oracle's own smallest eigenvalue of P decays from 3e-5 to
+    3e-9 within 4000 callbacks, so "100k steps" of this filter do not exist to compare against.
+    Oracle parity on a prefix, then properties of the state after 3000 callbacks."""
+    from oracle.c_oracle import CFilter
+
+    L, T, B = 64, 3_000, 2
+    tr = tg.make_traces(L, T, B=B, seed=3)
+    core, poses, dims = gpu_replay("ukf", tr, tg.dim_cap(L), chunk=1_000)
+    pre = 1000
+    o = CFilter("ukf", tg.dim_cap(L))
+    po, do = o.replay(sub_trajectory(tr[0], 0, pre))
+    assert np.array_equal(dims[0, :pre], do)
+    assert rel_err(poses[0, :pre], po) < REL_TOL
+    for b in range(B):
+        assert core.dim(b) == tg.full_dim(L) and core.status(b) == 0
+        X, Z, P = core.state(b)
+        assert np.isfinite(P).all()
+        assert np.abs(P - P.T).max() < 1e-9 * np.abs(P).max()
+        assert np.linalg.eigvalsh((P + P.T) / 2).min() > 0
+        err = np.hypot(poses[b, -500:, 0] - tr.truth[b, -500:, 0], poses[b, -500:, 1] - tr.truth[b, -500:, 1])
+        assert err.max() < 0.3
+        assert len(core.wait_list(b)[0]) == L
