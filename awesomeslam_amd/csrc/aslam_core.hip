@@ -261,7 +261,7 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         A_(dev_alloc(c, &d.wait_cnt, B * cfg->max_wait, c->owned));
         A_(dev_alloc(c, &d.wait_n, B, c->owned));
 #ifdef ASLAM_STAMPS
-        A_(dev_alloc(c, &d.dbg, 16, c->owned));
+        A_(dev_alloc(c, &d.dbg, 64, c->owned));
 #endif
 #if ASLAM_HAVE_UKF
         if (rc == ASLAM_OK && cfg->filter == ASLAM_UKF)
@@ -663,6 +663,15 @@ int aslam_debug_stamps(aslam_ctx *c, unsigned long long *out12)
         if (sync_ctx(c) != ASLAM_OK)
                 return ASLAM_ERR_HIP;
         HIP_TRY(hipMemcpy(out12, c->dv.dbg, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+/* diagnostic builds only: per-wave busy cycles inside cholesky_forward: [wave][panel, trailing/forward/factor] */
+int aslam_debug_wave_busy(aslam_ctx *c, unsigned long long *out24)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        HIP_TRY(hipMemcpy(out24, c->dv.dbg + 16, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return ASLAM_OK;
 }
 #endif

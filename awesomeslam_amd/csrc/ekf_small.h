@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                       *const sH = L.sH;
         SmallShared &sm = *L.sm;
 
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        const int tid = threadIdx.x;
         const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
         double *Pg = d.P + (size_t)b * NP * NP;
         const double r_meas = (double)KR, q_proc = (double)KQ;
@@ -167,16 +167,14 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                                 double v = Pg[(size_t)i * NP + j];
                                 if (i == j)
                                         v += (i < n) ? r_meas : 1.0;
-                                Lt[idx] = v;
+                                Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = v;
                         }
                 }
                 __syncthreads();
                 ASLAM_STAMP(4);
-                cholesky_tiles<NT>(Lt, Dinv, nt, tid, &sm.status);
+                // Kt = Pt S^-1 (rows of Pt are independent right-hand sides), u = Kt Y; r*Kt written back in place
+                cholesky_solve_rows<NT>(Pg, Pg, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status);
                 ASLAM_STAMP(5);
-                // Kt = Pt S^-1 (rows of Pt are independent right-hand sides), u = Kt Y
-                if (wave < nt)
-                        solve_row_block<NT>(Pg, Pg, wave, nt, Lt, Dinv, sY, sU, r_meas, lane);
                 __syncthreads();
                 ASLAM_STAMP(6);
                 // X = X + K Y = X + H^-1 u (ekf.cpp:309)

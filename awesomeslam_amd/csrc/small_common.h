@@ -3,7 +3,7 @@
 // f64-MFMA triangular solves.  The EKF design notes below apply to ekf_small.h; ukf_small.h has its own.
 //
 //
-// One 1024-thread workgroup (16 wave64) owns one filter ("trajectory") and runs whole callbacks of the
+// One 768-thread workgroup (12 wave64) owns one filter ("trajectory") and runs whole callbacks of the
 // reference node on the device:
 //     cbSensorLandmark ekf.cpp:102-114 -> updateZandA ekf.cpp:137-213 (association, wait-list, growth
 //     ekf.cpp:217-290) -> slam ekf.cpp:293-311
@@ -28,8 +28,9 @@
 
 namespace aslam
 {
-constexpr int SMALL_WG = 1024;
+constexpr int SMALL_WG = 768; // 12 wave64: 3 per SIMD -> 168 VGPRs per lane for the MFMA chains
 constexpr int SMALL_WAVES = SMALL_WG / 64;
+constexpr int TILE_LD = 17;            // see TLD below
 constexpr int SMALL_OBS_CAP = 128;  // LDS capacity for the stored sensor message
 constexpr int SMALL_WAIT_CAP = 512; // LDS capacity for new_landmark_wait
 
@@ -104,8 +105,8 @@ template <int NT> struct SmallLayout
         static constexpr int NTILES = NT * (NT + 1) / 2;
         // offsets in doubles
         static constexpr int oL = 0;
-        static constexpr int oDinv = oL + NTILES * 256;
-        static constexpr int oX = oDinv + NT * 256;
+        static constexpr int oDinv = oL + NTILES * 16 * TILE_LD;
+        static constexpr int oX = oDinv + NT * 16 * TILE_LD;
         static constexpr int oZ = oX + NP;
         static constexpr int oY = oZ + NP;
         static constexpr int oU = oY + NP;
@@ -129,6 +130,12 @@ template <int NT> struct SmallLayout
         static constexpr size_t total = oSm + sizeof(SmallShared);
 };
 
+// 16x16 tiles live in LDS with a row stride of 17 doubles: with 16 the MFMA operand pattern [l&15][k] puts the 16
+// lanes of a ds_read2_b64 lane group on ONE bank pair (row stride 128 B = 32 dwords): a 16-way conflict that made
+// LDS, not the MFMA pipe, the bound of the factorisation (measured; profiles/r01_phase_stamps.txt)
+constexpr int TLD = 17;
+constexpr int TSZ = 16 * TLD;
+
 __device__ __forceinline__ int tile_index(int ib, int jb)
 {
         return ib * (ib + 1) / 2 + jb;
@@ -144,7 +151,7 @@ __device__ __forceinline__ bool factor_diag_tile(double *T, double *Ti, int lane
         const int row = lane & 15;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-                a[c] = T[row * 16 + c];
+                a[c] = T[row * TLD + c];
         bool ok = true;
         double invd[16];
 #pragma unroll
@@ -182,8 +189,8 @@ __device__ __forceinline__ bool factor_diag_tile(double *T, double *Ti, int lane
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
                 {
-                        T[row * 16 + c] = (c <= row) ? a[c] : 0.0;
-                        Ti[c * 16 + row] = x[c]; // Linv(c, row): zero above the diagonal by construction
+                        T[row * TLD + c] = (c <= row) ? a[c] : 0.0;
+                        Ti[c * TLD + row] = x[c]; // Linv(c, row): zero above the diagonal by construction
                 }
         }
         return ok;
@@ -191,7 +198,7 @@ __device__ __forceinline__ bool factor_diag_tile(double *T, double *Ti, int lane
 
 // ------------------------------------------------------------------------------------------------------
 /// Blocked Cholesky of the nt x nt tile matrix in LDS (lower block triangle), in place, plus the inverses
-/// of the diagonal blocks.  All 16 waves take part; panel and trailing updates run on the f64 MFMA.
+/// of the diagonal blocks.  All waves take part; panel and trailing updates run on the f64 MFMA.
 template <int NT>
 __device__ __forceinline__ void cholesky_tiles(double *Lt, double *Dinv, int nt, int tid, uint32_t *status)
 {
@@ -201,7 +208,7 @@ __device__ __forceinline__ void cholesky_tiles(double *Lt, double *Dinv, int nt,
         {
                 if (wave == 0)
                 {
-                        const bool ok = factor_diag_tile(Lt + tile_index(kb, kb) * 256, Dinv + kb * 256, lane);
+                        const bool ok = factor_diag_tile(Lt + tile_index(kb, kb) * TSZ, Dinv + kb * TSZ, lane);
                         if (!ok && lane == 0)
                                 *status |= 4u; // ASLAM_ST_NOT_PD
                 }
@@ -209,18 +216,18 @@ __device__ __forceinline__ void cholesky_tiles(double *Lt, double *Dinv, int nt,
                 // panel: L(ib,kb) = S(ib,kb) * Linv(kb)^T
                 for (int ib = kb + 1 + wave; ib < nt; ib += SMALL_WAVES)
                 {
-                        double *S = Lt + tile_index(ib, kb) * 256;
-                        const double *Di = Dinv + kb * 256;
+                        double *S = Lt + tile_index(ib, kb) * TSZ;
+                        const double *Di = Dinv + kb * TSZ;
                         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                         {
                                 const int k = lg + 4 * s;
-                                acc = mfma_f64(S[li * 16 + k], Di[li * 16 + k], acc);
+                                acc = mfma_f64(S[li * TLD + k], Di[li * TLD + k], acc);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                                S[(lg + 4 * r) * 16 + li] = acc[r];
+                                S[(lg + 4 * r) * TLD + li] = acc[r];
                 }
                 __syncthreads();
                 // trailing update: S(ib,jb) -= L(ib,kb) L(jb,kb)^T for kb < jb <= ib
@@ -236,25 +243,408 @@ __device__ __forceinline__ void cholesky_tiles(double *Lt, double *Dinv, int nt,
                                 --i;
                         const int j = q - i * (i + 1) / 2;
                         const int ib = kb + 1 + i, jb = kb + 1 + j;
-                        double *S = Lt + tile_index(ib, jb) * 256;
-                        const double *Li = Lt + tile_index(ib, kb) * 256;
-                        const double *Lj = Lt + tile_index(jb, kb) * 256;
+                        double *S = Lt + tile_index(ib, jb) * TSZ;
+                        const double *Li = Lt + tile_index(ib, kb) * TSZ;
+                        const double *Lj = Lt + tile_index(jb, kb) * TSZ;
                         d4 acc;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                                acc[r] = S[(lg + 4 * r) * 16 + li];
+                                acc[r] = S[(lg + 4 * r) * TLD + li];
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                         {
                                 const int k = lg + 4 * s;
-                                acc = mfma_f64(-Li[li * 16 + k], Lj[li * 16 + k], acc);
+                                acc = mfma_f64(-Li[li * TLD + k], Lj[li * TLD + k], acc);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                                S[(lg + 4 * r) * 16 + li] = acc[r];
+                                S[(lg + 4 * r) * TLD + li] = acc[r];
                 }
                 __syncthreads();
         }
+}
+
+// ------------------------------------------------------------------------------------------------------
+/// 1/sqrt(x): v_rsq_f64 seed + one third-order Newton step (1-2 ulp; the pivot chain is the serial spine of the
+/// factorisation, and sqrt + divide cost about three times as much)
+__device__ __forceinline__ double rsqrt_newton(double x)
+{
+        double y = __builtin_amdgcn_rsq(x); // ~2^-26 relative
+        const double e = fma(-(x * y), y, 1.0);
+        return fma(y * e, fma(e, 0.375, 0.5), y); // third-order step: error ~ (5/16) e^3, far below 2^-53
+}
+
+/// As factor_diag_tile, tuned for the 32-cycle dependent-f64 latency of gfx950: pivots through rsqrt_newton, and
+/// the inverse is built INSIDE the pivot loop (outer-product form): lane c carries column c of L^-1 as running sums
+/// s[i]; once column j of L is final, x_j = s[j] / L(j,j) and s[i] -= L(i,j) x_j use the very multipliers
+/// L(i,j) the factorisation has just broadcast, and none of that work sits on the pivot dependency chain.
+/// One wave (all 64 lanes run; lanes 16-63 mirror rows/columns 0-15).
+__device__ __forceinline__ bool factor_diag_tile_fast(double *T, double *Ti, int lane)
+{
+        double a[16], s[16];
+        const int row = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+        {
+                a[c] = T[row * TLD + c];
+                s[c] = (row == c) ? 1.0 : 0.0;
+        }
+        // Hand-scheduled: left to itself hipcc sinks the rank-1 updates into lazy dot-product chains (one dependent
+        // 32-cycle v_fma_f64 per earlier column in front of every pivot) and spills the broadcast multipliers.  Here
+        // column j's updates are issued eagerly, the critical one (row/column j+1) first, and the remaining ones fill
+        // the latency gaps of the NEXT pivot's rsqrt chain; sched_barrier pins that order.
+#define ASLAM_UPD(c)                                                                                                   \
+        if ((c) < 16)                                                                                                  \
+        {                                                                                                              \
+                const double lc_ = readlane_f64(lij, ((c) < 16) ? (c) : 15);                                           \
+                a[((c) < 16) ? (c) : 15] = fma(-lij, lc_, a[((c) < 16) ? (c) : 15]);                                   \
+                s[((c) < 16) ? (c) : 15] = fma(-lc_, xj, s[((c) < 16) ? (c) : 15]);                                    \
+                asm volatile("" : "+v"(a[((c) < 16) ? (c) : 15]), "+v"(s[((c) < 16) ? (c) : 15])); /* no sinking */   \
+        }
+        const double d0 = readlane_f64(a[0], 0);
+        bool ok = d0 > 0.0;
+        double inv = readfirstlane_f64(rsqrt_newton(d0));
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+                const double lij = a[j] * inv; // L(i,j) for i >= j
+                const double xj = s[j] * inv;  // (L^-1)(j, lane)
+                a[j] = lij;
+                s[j] = xj;
+                double d = 1.0, y = 1.0, t = 0.0, e = 0.0, ye = 0.0, pp = 0.0, invn = 1.0;
+                __builtin_amdgcn_sched_barrier(0);
+                ASLAM_UPD(j + 1);
+                if (j + 1 < 16)
+                {
+                        d = readlane_f64(a[(j + 1 < 16) ? j + 1 : 15], (j + 1 < 16) ? j + 1 : 15);
+                        ok = ok && (d > 0.0);
+                        y = __builtin_amdgcn_rsq(d);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                t = d * y;
+                ASLAM_UPD(j + 2);
+                ASLAM_UPD(j + 3);
+                ASLAM_UPD(j + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                e = fma(-t, y, 1.0);
+                ASLAM_UPD(j + 5);
+                ASLAM_UPD(j + 6);
+                ASLAM_UPD(j + 7);
+                __builtin_amdgcn_sched_barrier(0);
+                ye = y * e;
+                pp = fma(e, 0.375, 0.5);
+                ASLAM_UPD(j + 8);
+                ASLAM_UPD(j + 9);
+                ASLAM_UPD(j + 10);
+                __builtin_amdgcn_sched_barrier(0);
+                invn = fma(ye, pp, y);
+                ASLAM_UPD(j + 11);
+                ASLAM_UPD(j + 12);
+                ASLAM_UPD(j + 13);
+                ASLAM_UPD(j + 14);
+                ASLAM_UPD(j + 15);
+                __builtin_amdgcn_sched_barrier(0);
+                inv = readfirstlane_f64(invn);
+        }
+#undef ASLAM_UPD
+        if (lane < 16)
+        {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                {
+                        T[row * TLD + c] = (c <= row) ? a[c] : 0.0;
+                        Ti[c * TLD + row] = s[c]; // Linv(c, row): zero above the diagonal by construction
+                }
+        }
+        return ok;
+}
+
+/// Load the 16 rows [16 rb, 16 rb + 16) of Src (row-major, stride NP) into MFMA accumulator layout, transposed:
+/// acc[cb][r] of lane l = Src[16 rb + (l&15)][16 cb + (l>>4) + 4 r].
+template <int NT> __device__ __forceinline__ void load_row_block(d4 (&acc)[NT], const double *Src, int rb, int nt, int lane)
+{
+        constexpr int NP = 16 * NT;
+        const double *rowp = Src + (size_t)(16 * rb + (lane & 15)) * NP + (lane >> 4);
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb)
+        {
+                if (cb < nt)
+                {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                acc[cb][r] = rowp[16 * cb + 4 * r];
+                }
+        }
+}
+
+// ---- pieces of the fused factorisation, shared by the three wave roles below -------------------------------
+/// this wave's share of panel kb: L(ib,kb) = S(ib,kb) * Linv(kb)^T for ib = kb+1+wave, +SMALL_WAVES, ...
+__device__ __forceinline__ void chol_panel_share(double *Lt, const double *Dinv, int nt, int kb, int wave, int li, int lg)
+{
+        for (int ib = kb + 1 + wave; ib < nt; ib += SMALL_WAVES)
+        {
+                double *S = Lt + tile_index(ib, kb) * TSZ;
+                const double *Di = Dinv + kb * TSZ;
+                double sa[4], sb[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                        sa[s] = S[li * TLD + lg + 4 * s];
+                        sb[s] = Di[li * TLD + lg + 4 * s];
+                }
+                d4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                        t = mfma_f64(sa[s], sb[s], t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                        S[(lg + 4 * r) * TLD + li] = t[r];
+        }
+}
+
+/// this wave's share of the trailing update after panel kb: S(ib,jb) -= L(ib,kb) L(jb,kb)^T for kb < jb <= ib, without
+/// (kb+1,kb+1), which belongs to the diagonal wave; `widx` in [0, SMALL_WAVES-1) numbers the non-diagonal waves
+__device__ __forceinline__ void chol_trailing_share(double *Lt, int nt, int kb, int widx, int li, int lg)
+{
+        const int m = nt - kb - 1;
+        const int ntr = m * (m + 1) / 2;
+        for (int q = 1 + widx; q < ntr; q += SMALL_WAVES - 1)
+        {
+                int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= q)
+                        ++i;
+                while (i * (i + 1) / 2 > q)
+                        --i;
+                const int j = q - i * (i + 1) / 2;
+                const int ib = kb + 1 + i, jb = kb + 1 + j;
+                double *S = Lt + tile_index(ib, jb) * TSZ;
+                const double *Li = Lt + tile_index(ib, kb) * TSZ;
+                const double *Lj = Lt + tile_index(jb, kb) * TSZ;
+                double la[4], lb[4];
+                d4 t;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                        la[s] = Li[li * TLD + lg + 4 * s];
+                        lb[s] = Lj[li * TLD + lg + 4 * s];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                        t[r] = S[(lg + 4 * r) * TLD + li];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                        t = mfma_f64(-la[s], lb[s], t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                        S[(lg + 4 * r) * TLD + li] = t[r];
+        }
+}
+
+/// forward substitution step for block column kb on the row block in acc: acc[kb] <- Linv(kb) acc[kb], then
+/// acc[c2] -= L(c2,kb) acc[kb] for c2 > kb, two independent accumulators in flight
+template <int NT>
+__device__ __forceinline__ void forward_step(d4 (&acc)[NT], const double *Lt, const double *Dinv, int nt, int kb, int li, int lg)
+{
+        const double *Di = Dinv + kb * TSZ;
+        double da[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+                da[s] = Di[li * TLD + lg + 4 * s];
+        d4 v = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb)
+        {
+                if (cb == kb)
+                {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                v = mfma_f64(da[s], acc[cb][s], v);
+                        acc[cb] = v;
+                }
+        }
+        const d4 vn = -v;
+#pragma unroll
+        for (int c2 = 1; c2 < NT; c2 += 2)
+        {
+                const bool on0 = (c2 > kb && c2 < nt), on1 = (c2 + 1 > kb && c2 + 1 < nt && c2 + 1 < NT);
+                double la[4], lb[4];
+                if (on0)
+                {
+                        const double *Lc = Lt + tile_index(c2, kb) * TSZ;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                la[s] = Lc[li * TLD + lg + 4 * s];
+                }
+                if (on1)
+                {
+                        const double *Lc = Lt + tile_index(c2 + 1, kb) * TSZ;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                lb[s] = Lc[li * TLD + lg + 4 * s];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                        if (on0)
+                                acc[c2] = mfma_f64(la[s], vn[s], acc[c2]);
+                        if (on1)
+                                acc[(c2 + 1 < NT) ? c2 + 1 : c2] = mfma_f64(lb[s], vn[s], acc[(c2 + 1 < NT) ? c2 + 1 : c2]);
+                }
+        }
+}
+
+/// look-ahead of the diagonal wave after panel kb: update tile (kb+1,kb+1) with L(kb+1,kb) and factor it
+__device__ __forceinline__ bool chol_lookahead(double *Lt, double *Dinv, int nt, int kb, int lane, int li, int lg)
+{
+        if (kb + 1 >= nt)
+                return true;
+        double *S = Lt + tile_index(kb + 1, kb + 1) * TSZ;
+        const double *Li = Lt + tile_index(kb + 1, kb) * TSZ;
+        double la[4];
+        d4 t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+                la[s] = Li[li * TLD + lg + 4 * s];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+                t[r] = S[(lg + 4 * r) * TLD + li];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+                t = mfma_f64(-la[s], la[s], t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+                S[(lg + 4 * r) * TLD + li] = t[r];
+        return factor_diag_tile_fast(S, Dinv + (kb + 1) * TSZ, lane);
+}
+
+/// Backward substitution on the row block held in acc: acc <- (acc^T L^-1)^T, then u[row] = result . Y and
+/// Dst[rows] = scale * result.  One wave; operands of a whole block step are fetched before its MFMAs.
+template <int NT>
+__device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int rb, int nt, const double *Lt, const double *Dinv,
+                                               const double *Y, double *U, double scale, int lane)
+{
+        constexpr int NP = 16 * NT;
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int cb = NT - 1; cb >= 0; --cb)
+        {
+                if (cb < nt)
+                {
+                        const double *Di = Dinv + cb * TSZ;
+                        double da[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                da[s] = Di[(lg + 4 * s) * TLD + li];
+                        d4 v = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                v = mfma_f64(da[s], acc[cb][s], v);
+                        acc[cb] = v;
+                        const d4 vn = -v;
+#pragma unroll
+                        for (int c2 = 0; c2 < cb; c2 += 2)
+                        {
+                                const double *L0 = Lt + tile_index(cb, c2) * TSZ;
+                                double l0[4], l1[4];
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                        l0[s] = L0[(lg + 4 * s) * TLD + li];
+                                if (c2 + 1 < cb)
+                                {
+                                        const double *L1 = Lt + tile_index(cb, c2 + 1) * TSZ;
+#pragma unroll
+                                        for (int s = 0; s < 4; ++s)
+                                                l1[s] = L1[(lg + 4 * s) * TLD + li];
+                                }
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                {
+                                        acc[c2] = mfma_f64(l0[s], vn[s], acc[c2]);
+                                        if (c2 + 1 < cb)
+                                                acc[c2 + 1] = mfma_f64(l1[s], vn[s], acc[c2 + 1]);
+                                }
+                        }
+                }
+        }
+        double part = 0.0;
+        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb)
+        {
+                if (cb < nt)
+                {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                part = fma(acc[cb][r], Y[16 * cb + lg + 4 * r], part);
+                                outp[16 * cb + 4 * r] = acc[cb][r] * scale;
+                        }
+                }
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (lg == 0)
+                U[16 * rb + li] = part;
+}
+
+/// Dst = scale * Src S^-1 for all rows (Src, Dst row-major HBM with stride NP, may alias; S = lower tiles in Lt, which
+/// leaves as its Cholesky factor), u = (Src S^-1) Y.  The whole workgroup takes part, in three wave roles that
+/// run their own loops with the same barrier sequence (so that each role gets its own register allocation):
+///   * waves 0 .. nt-1 ("row-block waves"): 16 right-hand-side rows each in MFMA accumulators; the forward substitution
+///     rides along with the factorisation (step kb as soon as panel kb exists), the backward one follows;
+///   * wave NT ("diagonal wave"): factors diagonal tile kb+1 (look-ahead) while the others do the trailing update
+///     and the forward step of block column kb, so the serial 16x16 factorisations leave the critical path;
+///   * the remaining waves only help with panel / trailing tiles.
+/// Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
+                                                    const double *Y, double *U, double scale, int tid, uint32_t *status)
+{
+        static_assert(NT < SMALL_WAVES, "one wave beyond the row-block waves is needed for the diagonal tiles");
+        constexpr int DW = NT;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // scalar: the role branches are uniform
+        const int li = lane & 15, lg = lane >> 4;
+        if (wave < nt)
+        {
+                d4 acc[NT];
+                load_row_block<NT>(acc, Src, wave, nt, lane);
+                __syncthreads(); // (the diagonal wave factors tile 0)
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
+                        chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        __syncthreads();
+                }
+                backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
+        }
+        else if (wave == DW)
+        {
+                bool ok = factor_diag_tile_fast(Lt, Dinv, lane);
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        ok = chol_lookahead(Lt, Dinv, nt, kb, lane, li, lg) && ok;
+                        __syncthreads();
+                }
+                if (!ok && lane == 0)
+                        *status |= 4u; // ASLAM_ST_NOT_PD
+        }
+        else
+        {
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        __syncthreads();
+                }
+        }
+        __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -286,21 +676,21 @@ __device__ __forceinline__ void solve_row_block(const double *Src, double *Dst, 
         {
                 if (cb < nt)
                 {
-                        const double *Di = Dinv + cb * 256;
+                        const double *Di = Dinv + cb * TSZ;
                         d4 v = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                                v = mfma_f64(Di[li * 16 + lg + 4 * s], acc[cb][s], v);
+                                v = mfma_f64(Di[li * TLD + lg + 4 * s], acc[cb][s], v);
                         acc[cb] = v;
 #pragma unroll
                         for (int c2 = cb + 1; c2 < NT; ++c2)
                         {
                                 if (c2 < nt)
                                 {
-                                        const double *Lc = Lt + tile_index(c2, cb) * 256;
+                                        const double *Lc = Lt + tile_index(c2, cb) * TSZ;
 #pragma unroll
                                         for (int s = 0; s < 4; ++s)
-                                                acc[c2] = mfma_f64(-Lc[li * 16 + lg + 4 * s], v[s], acc[c2]);
+                                                acc[c2] = mfma_f64(-Lc[li * TLD + lg + 4 * s], v[s], acc[c2]);
                                 }
                         }
                 }
@@ -311,19 +701,19 @@ __device__ __forceinline__ void solve_row_block(const double *Src, double *Dst, 
         {
                 if (cb < nt)
                 {
-                        const double *Di = Dinv + cb * 256;
+                        const double *Di = Dinv + cb * TSZ;
                         d4 v = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                                v = mfma_f64(Di[(lg + 4 * s) * 16 + li], acc[cb][s], v);
+                                v = mfma_f64(Di[(lg + 4 * s) * TLD + li], acc[cb][s], v);
                         acc[cb] = v;
 #pragma unroll
                         for (int c2 = 0; c2 < cb; ++c2)
                         {
-                                const double *Lc = Lt + tile_index(cb, c2) * 256;
+                                const double *Lc = Lt + tile_index(cb, c2) * TSZ;
 #pragma unroll
                                 for (int s = 0; s < 4; ++s)
-                                        acc[c2] = mfma_f64(-Lc[(lg + 4 * s) * 16 + li], v[s], acc[c2]);
+                                        acc[c2] = mfma_f64(-Lc[(lg + 4 * s) * TLD + li], v[s], acc[c2]);
                         }
                 }
         }

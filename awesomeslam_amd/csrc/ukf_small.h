@@ -1,6 +1,6 @@
 // ukf_small.h -- fused per-trajectory UKF-SLAM kernel for state dimensions that fit one CU (n <= 16*NT <= 144).
 //
-// One 1024-thread workgroup owns one filter and runs whole callbacks of the reference's UKF node:
+// One 768-thread workgroup owns one filter and runs whole callbacks of the reference's UKF node:
 //     cbSensorLandmark ukf.cpp:98-110 -> updateZ ukf.cpp:113-180 (+ wait-list, growth ukf.cpp:184-257) -> slam ukf.cpp:260-392
 // (the front end is shared with the EKF: small_common.h).
 //
@@ -48,7 +48,7 @@ template <int NT> struct UkfLayout
         // P is dead by then, and at NT = 9 there is no room for both); smaller NT get an area of their own.
         static constexpr int SLAB_LD = 17;                  // doubles per slab row (16 + 1 pad: conflict-free MFMA operand reads)
         static constexpr int SLAB = NP * SLAB_LD;           // doubles per slab
-        static constexpr bool STAGE_OVERLAYS_TILES = (4 * SLAB <= LY::NTILES * 256);
+        static constexpr bool STAGE_OVERLAYS_TILES = (4 * SLAB <= LY::NTILES * TSZ);
         static constexpr size_t oZv = oZpred + 8 * NP;                 // double[NP] z = sqrt(-w0) dz_0 (rank-1 part of S)
         static constexpr size_t oVv = oZv + 8 * NP;                    // double[NP] v = S+^-1 z
         static constexpr size_t oGv = oVv + 8 * NP;                    // double[NP] g = K+ z
@@ -197,7 +197,7 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                                         double v = acc[q][r];
                                         if (i == j)
                                                 v += (i < n_true) ? diag_add : 1.0;
-                                        Ct[tile_index(ib, jb) * 256 + (lg + 4 * r) * 16 + li] = v;
+                                        Ct[tile_index(ib, jb) * TSZ + (lg + 4 * r) * TLD + li] = v;
                                 }
                                 else if (MODE == GEMM_STORE)
                                         Cg[(size_t)i * NP + j] = acc[q][r];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                 double v = Pg[(size_t)i * NP + j];
                                 if (i == j && i >= n)
                                         v = 1.0;
-                                Lt[idx] = v;
+                                Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = v;
                         }
                 }
                 __syncthreads();
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
 
                 // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)
                 auto Lkc = [&](int k, int c) -> double {
-                        return (c <= k) ? Lt[tile_index(k >> 4, c >> 4) * 256 + (k & 15) * 16 + (c & 15)] : 0.0;
+                        return (c <= k) ? Lt[tile_index(k >> 4, c >> 4) * TSZ + (k & 15) * TLD + (c & 15)] : 0.0;
                 };
                 // sigma point i -> (column c of Laug, sign); i = 0 is the mean itself
                 auto col_of = [&](int i, int &c, double &sg) {
