@@ -173,7 +173,12 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 __syncthreads();
                 ASLAM_STAMP(4);
                 // Kt = Pt S^-1 (rows of Pt are independent right-hand sides), u = Kt Y; r*Kt written back in place
+                #ifdef ASLAM_STAMPS
+                cholesky_solve_rows<NT>(Pg, Pg, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status,
+                                        (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr);
+#else
                 cholesky_solve_rows<NT>(Pg, Pg, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status);
+#endif
                 ASLAM_STAMP(5);
                 __syncthreads();
                 ASLAM_STAMP(6);

@@ -126,7 +126,10 @@ template <int NT> struct SmallLayout
         static constexpr size_t oWy = oWx + 4 * SMALL_WAIT_CAP;
         static constexpr size_t oWc = oWy + 4 * SMALL_WAIT_CAP;        // uint count
         static constexpr size_t oNew = oWc + 4 * SMALL_WAIT_CAP;       // int[NP/2] wait entries promoted this callback
-        static constexpr size_t oSm = (oNew + 4 * (NP / 2) + 15) & ~(size_t)15;
+        static constexpr size_t oPd = oNew + 4 * (NP / 2);             // float[OBS_CAP][4] partial nearest distances
+        static constexpr size_t oPi = oPd + 16 * SMALL_OBS_CAP;        // int  [OBS_CAP][4] partial nearest indices
+        static constexpr size_t oLm = oPi + 16 * SMALL_OBS_CAP;        // float[NP/2][2] mapped landmarks narrowed to binary32
+        static constexpr size_t oSm = (oLm + 8 * (NP / 2) + 15) & ~(size_t)15;
         static constexpr size_t total = oSm + sizeof(SmallShared);
 };
 
@@ -598,8 +601,15 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
 /// Ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
-                                                    const double *Y, double *U, double scale, int tid, uint32_t *status)
+                                                    const double *Y, double *U, double scale, int tid, uint32_t *status,
+                                                    unsigned long long *wave_busy = nullptr)
 {
+#ifdef ASLAM_STAMPS
+        unsigned long long tb_[3] = {0, 0, 0}, tm_ = __builtin_amdgcn_s_memtime(), tn_;
+#define WB(i) (tn_ = __builtin_amdgcn_s_memtime(), tb_[i] += tn_ - tm_, tm_ = tn_)
+#else
+#define WB(i)
+#endif
         static_assert(NT < SMALL_WAVES, "one wave beyond the row-block waves is needed for the diagonal tiles");
         constexpr int DW = NT;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // scalar: the role branches are uniform
@@ -611,13 +621,19 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 __syncthreads(); // (the diagonal wave factors tile 0)
                 for (int kb = 0; kb < nt; ++kb)
                 {
+                        WB(1);
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
+                        WB(1);
                         forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
                         chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
                 }
+                WB(1);
                 backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
+                WB(2);
         }
         else if (wave == DW)
         {
@@ -625,11 +641,16 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 __syncthreads();
                 for (int kb = 0; kb < nt; ++kb)
                 {
+                        WB(1);
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
+                        WB(1);
                         ok = chol_lookahead(Lt, Dinv, nt, kb, lane, li, lg) && ok;
+                        WB(0);
                         __syncthreads();
                 }
+                WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
         }
@@ -638,12 +659,25 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 __syncthreads();
                 for (int kb = 0; kb < nt; ++kb)
                 {
+                        WB(1);
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
+                        WB(1);
                         chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        WB(0);
                         __syncthreads();
                 }
+                WB(1);
         }
+#ifdef ASLAM_STAMPS
+        if (wave_busy && lane == 0)
+        {
+                wave_busy[2 * wave] += tb_[0];      // busy inside the factorisation loop
+                wave_busy[2 * wave + 1] += tb_[2];  // backward substitution + store
+        }
+#endif
+#undef WB
         __syncthreads();
 }
 
@@ -748,6 +782,9 @@ struct SmallLds
         float *sWr, *sWb, *sWx, *sWy;
         uint32_t *sWc;
         int *sNew;
+        float *sPd;
+        int *sPi;
+        float *sLm;
         SmallShared *sm;
 };
 
@@ -775,6 +812,9 @@ template <int NT> __device__ __forceinline__ SmallLds small_carve(unsigned char 
         L.sWy = reinterpret_cast<float *>(smem + LY::oWy);
         L.sWc = reinterpret_cast<uint32_t *>(smem + LY::oWc);
         L.sNew = reinterpret_cast<int *>(smem + LY::oNew);
+        L.sPd = reinterpret_cast<float *>(smem + LY::oPd);
+        L.sPi = reinterpret_cast<int *>(smem + LY::oPi);
+        L.sLm = reinterpret_cast<float *>(smem + LY::oLm);
         L.sm = reinterpret_cast<SmallShared *>(smem + LY::oSm);
         return L;
 }
@@ -872,7 +912,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         int *const sCid = L.sCid, *const sNew = L.sNew;
         float *const sWr = L.sWr, *const sWb = L.sWb, *const sWx = L.sWx, *const sWy = L.sWy;
         uint32_t *const sWc = L.sWc;
-        const int wave = tid >> 6, lane = tid & 63;
+        (void)0;
         // ================= message intake
         if (tid == 0)
         {
@@ -940,62 +980,74 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 sPx[j] = a;
                 sPy[j] = c;
         }
-        __syncthreads();
-        // nearest mapped landmark of every observation (ekf.cpp:159-173): one wave per observation,
-        // lanes over landmarks; ties and NaNs resolve as the sequential `dist < mindist` scan does
-        for (int j = wave; j < sm.sn; j += SMALL_WAVES)
+        for (int k = tid; k < nl; k += SMALL_WG)
         {
+                L.sLm[2 * k] = (float)sX[3 + 2 * k]; // Point(const float &, const float &), structures.h:50
+                L.sLm[2 * k + 1] = (float)sX[4 + 2 * k];
+        }
+        __syncthreads();
+        // nearest mapped landmark of every observation (ekf.cpp:159-173).  Four threads per observation scan a quarter
+        // of the landmarks each, in index order with the reference's strict `dist < mindist`; the quarters are then
+        // combined in order, so ties, infinities and NaNs resolve exactly as in the sequential scan.
+        const int chunk = (nl + 3) >> 2;
+        for (int idx = tid; idx < 4 * sm.sn; idx += SMALL_WG)
+        {
+                const int j = idx >> 2, c = idx & 3;
+                const int k0 = c * chunk, k1 = min(nl, k0 + chunk);
+                const float ox = sPx[j], oy = sPy[j];
                 float bd = __builtin_inff();
-                int bk = 0x7fffffff;
-                float d0 = 0.0f;
-                for (int k = lane; k < nl; k += 64)
+                int bk = -1;
+                for (int k = k0; k < k1; ++k)
                 {
-                        const float dd = eulerDistance(sPx[j], sPy[j], (float)sX[3 + 2 * k], (float)sX[4 + 2 * k]);
-                        if (k == 0)
-                                d0 = dd;
-                        if (dd < bd)
+                        const float dd = eulerDistance(ox, oy, L.sLm[2 * k], L.sLm[2 * k + 1]);
+                        if (k == 0 || dd < bd) // mindist starts as the distance to landmark 0, whatever it is
                         {
                                 bd = dd;
                                 bk = k;
                         }
                 }
+                L.sPd[idx] = bd;
+                L.sPi[idx] = bk;
+        }
+        for (int k = tid; k < nl; k += SMALL_WG)
+                sNew[k] = -1; // last observation associated with landmark k
+        __syncthreads();
+        for (int j = tid; j < sm.sn; j += SMALL_WG)
+        {
+                float bd = L.sPd[4 * j];
+                int bk = L.sPi[4 * j];
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1)
+                for (int c = 1; c < 4; ++c)
                 {
-                        const float od = __shfl_xor(bd, off);
-                        const int ok = __shfl_xor(bk, off);
-                        if (od < bd || (od == bd && ok < bk))
+                        const float od = L.sPd[4 * j + c];
+                        if (L.sPi[4 * j + c] >= 0 && od < bd)
                         {
                                 bd = od;
-                                bk = ok;
+                                bk = L.sPi[4 * j + c];
                         }
                 }
-                d0 = __shfl(d0, 0);
-                if (lane == 0)
+                if (nl == 0)
                 {
-                        if (nl == 0)
-                        {
-                                sMd[j] = __builtin_inff();
-                                sCid[j] = 0;
-                                sm.any_miss = 1;
-                        }
-                        else
-                        {
-                                if (d0 != d0 || bk == 0x7fffffff)
-                                {
-                                        // mindist starts as dist(landmark 0); a NaN there is never replaced,
-                                        // and an all-inf scan keeps corr_id = 0
-                                        bd = d0;
-                                        bk = 0;
-                                }
-                                sMd[j] = bd;
-                                sCid[j] = 2 * bk;
-                                if (!(bd < MIN_DIST_THRESH))
-                                        sm.any_miss = 1;
-                        }
+                        bd = __builtin_inff();
+                        bk = 0;
                 }
+                sMd[j] = bd;
+                sCid[j] = 2 * bk;
+                if (n0 != 3 && bd < MIN_DIST_THRESH)
+                        atomicMax(&sNew[bk], j); // observations are walked in order: the last one wins (ekf.cpp:175-181)
+                else
+                        sm.any_miss = 1;
         }
         __syncthreads();
+        // associated observations: Z(3 + corr_id) = range, Z(4 + corr_id) = bearing
+        for (int j = tid; j < sm.sn; j += SMALL_WG)
+        {
+                if (n0 != 3 && sMd[j] < MIN_DIST_THRESH && sNew[sCid[j] >> 1] == j)
+                {
+                        sZ[3 + sCid[j]] = (double)sSr[j];
+                        sZ[4 + sCid[j]] = (double)sSb[j];
+                }
+        }
         if (sm.any_miss)
         {
                 // wait-list entries re-projected from the current pose (ekf.cpp:229,233)
@@ -1008,18 +1060,16 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 }
         }
         __syncthreads();
-        if (tid == 0)
+        if (tid == 0 && sm.any_miss)
         {
+                // unassociated observations go through the wait-list in message order (they touch nothing the associated
+                // ones touch); counts only change here, so without a miss there is nothing to promote either
                 int wn = sm.wn;
                 const int wcap = min(d.max_wait, SMALL_WAIT_CAP);
                 for (int j = 0; j < sm.sn; ++j)
                 {
                         if (n0 != 3 && sMd[j] < MIN_DIST_THRESH)
-                        {
-                                sZ[3 + sCid[j]] = (double)sSr[j];
-                                sZ[4 + sCid[j]] = (double)sSb[j];
                                 continue;
-                        }
                         // updateNewLandmarkWait, ekf.cpp:217-253
                         bool push = (wn == 0);
                         if (!push)
@@ -1090,6 +1140,9 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                                 sm.grew = 1;
                         }
                 }
+        }
+        if (tid == 0)
+        {
                 // Update A, ekf.cpp:206-212 (the UKF node has no A)
                 if (IS_EKF && sm.tvx != 0.0 && sm.twz != 0.0)
                 {
