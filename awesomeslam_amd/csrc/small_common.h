@@ -681,6 +681,42 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
         __syncthreads();
 }
 
+/// Cholesky factorisation of the tile matrix alone (Lt -> L, Dinv -> inverted diagonal blocks), same look-ahead
+/// scheme as cholesky_solve_rows: wave NT factors diagonal tile kb+1 while the others update the trailing tiles.
+template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt, double *Dinv, int nt, int tid, uint32_t *status)
+{
+        static_assert(NT < SMALL_WAVES, "one wave is reserved for the diagonal tiles");
+        constexpr int DW = NT;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int li = lane & 15, lg = lane >> 4;
+        if (wave == DW)
+        {
+                bool ok = factor_diag_tile_fast(Lt, Dinv, lane);
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        ok = chol_lookahead(Lt, Dinv, nt, kb, lane, li, lg) && ok;
+                        __syncthreads();
+                }
+                if (!ok && lane == 0)
+                        *status |= 4u; // ASLAM_ST_NOT_PD
+        }
+        else
+        {
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        __syncthreads();
+                }
+        }
+        __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------------
 /// Dst = scale * Src S^-1 for the 16 rows [16*rb, 16*rb+16) (Src, Dst: row-major HBM, stride NP; may alias);
 /// also u[row] = (Src S^-1)[row,:] . Y (unscaled).  One wave.  The row block is held transposed in MFMA

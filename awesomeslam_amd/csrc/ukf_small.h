@@ -65,7 +65,7 @@ enum
 
 /// C (op)= A diag(w) B^T over k = 0 .. 16*nks-1 (SKIP_K0: without the k = 0 term).  A, B: row-major HBM with row stride ld (>= 16*nks), rows
 /// [0, 16*nt).  w: LDS weights or nullptr.  All 1024 threads of the workgroup take part; `stage` is 4*SLAB doubles
-/// of LDS.  Output tiles are dealt round-robin to the 16 waves (<= TPW per wave).
+/// of LDS.  Output tiles are dealt round-robin to the waves (<= TPW per wave).
 template <int NT, int MODE, bool SKIP_K0 = false>
 __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int ld, int nks, const double *w, int nt,
                                           double *Cg, double *Ct, double diag_add, int n_true, double *stage, int tid)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
         double *const stage = UL::STAGE_OVERLAYS_TILES ? Lt : reinterpret_cast<double *>(smem + UL::oStage);
         SmallShared &sm = *L.sm;
 
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        const int tid = threadIdx.x;
         const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
         const int MP = uv.MP;
         double *Pg = d.P + (size_t)b * NP * NP;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         }
                 }
                 __syncthreads();
-                cholesky_tiles<NT>(Lt, Dinv, nt, tid, &sm.status);
+                cholesky_lookahead<NT>(Lt, Dinv, nt, tid, &sm.status);
 
                 // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)
                 auto Lkc = [&](int k, int c) -> double {
@@ -429,10 +429,47 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 }
                 __syncthreads();
 
-                // ---- P = sum w d d^T + Q, ukf.cpp:307-319 (tile region of LDS becomes GEMM staging: L is dead)
-                gemm_wabt<NT, GEMM_STORE>(Dg, Dg, MP, mt, sW, nt, Pg, nullptr, 0.0, n, stage, tid);
-                if (tid < 3)
-                        Pg[(size_t)tid * NP + tid] += q_proc;
+                // ---- P = sum w d d^T + Q, ukf.cpp:307-319.  For two landmark entries a, b the sigma points are affine,
+                // d_i(a) = +-w L(a,c_i) + delta_a with delta_a = X(a) - Xbar(a) (not zero: the binary32 weights do not sum to 1),
+                // so the +- pairs cancel and, exactly,  sum_i w_i d_i(a) d_i(b) = (sum_i w_i) delta_a delta_b + 2 w_1 w^2 (L L^T)(a,b),
+                // with L L^T = P, the covariance that was just factored: an in-place scale + rank-1 term instead of a GEMM.
+                // Rows / columns of the three pose entries are nonlinear and are summed explicitly over the 2N+5 columns.
+                {
+                        double wsum = w_0;
+                        for (int i = 1; i < m; ++i)
+                                wsum += w_i;
+                        const double cll = 2.0 * w_i * wsp * wsp;
+                        for (int idx = tid; idx < n * n; idx += SMALL_WG)
+                        {
+                                const int a = idx / n, bb = idx - a * n;
+                                if (a >= 3 && bb >= 3)
+                                {
+                                        const double da = sX[a] - sXbar[a], db = sX[bb] - sXbar[bb];
+                                        Pg[(size_t)a * NP + bb] = fma(cll, Pg[(size_t)a * NP + bb], wsum * da * db);
+                                }
+                        }
+                        for (int idx = tid; idx < 3 * n; idx += SMALL_WG)
+                        {
+                                const int a = idx / n, bb = idx - a * n;
+                                const double *ra = Dg + (size_t)a * MP, *rb = Dg + (size_t)bb * MP;
+                                double acc0 = 0.0, acc1 = 0.0;
+                                int i = 0;
+                                for (; i + 1 < m; i += 2)
+                                {
+                                        acc0 = fma(sW[i] * ra[i], rb[i], acc0);
+                                        acc1 = fma(sW[i + 1] * ra[i + 1], rb[i + 1], acc1);
+                                }
+                                if (i < m)
+                                        acc0 = fma(sW[i] * ra[i], rb[i], acc0);
+                                double v = acc0 + acc1;
+                                if (a == bb)
+                                        v += q_proc;
+                                Pg[(size_t)a * NP + bb] = v;
+                                if (bb >= 3)
+                                        Pg[(size_t)bb * NP + a] = v; // mirror (the reference's two roundings differ in the last bit only)
+                        }
+                }
+                __syncthreads();
 
                 // ---- Zpred = sum w Zsig, bearings wrapped (ukf.cpp:329-339); innovation Zdiff (ukf.cpp:381-386)
                 for (int k = tid; k < NP; k += SMALL_WG)
@@ -482,11 +519,9 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 // z rides along as right-hand side row n (n is odd, so row n is always a padding row of the last tile)
                 for (int j = tid; j < 16 * nt; j += SMALL_WG)
                         Tcg[(size_t)n * NP + j] = sZv[j];
-                cholesky_tiles<NT>(Lt, Dinv, nt, tid, &sm.status);
-                // ---- K+ = Tc S+^-1 (and v^T = z^T S+^-1 in row n), u+ = K+ Zdiff
-                if (wave < nt)
-                        solve_row_block<NT>(Tcg, Kg, wave, nt, Lt, Dinv, sY, sU, 1.0, lane);
                 __syncthreads();
+                // ---- K+ = Tc S+^-1 (and v^T = z^T S+^-1 in row n), u+ = K+ Zdiff: fused Cholesky + row-block solves
+                cholesky_solve_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, 1.0, tid, &sm.status);
                 for (int j = tid; j < NP; j += SMALL_WG)
                         sVv[j] = (j < 16 * nt) ? Kg[(size_t)n * NP + j] : 0.0;
                 for (int a = tid; a < NP; a += SMALL_WG)
