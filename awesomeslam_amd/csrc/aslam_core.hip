@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ekf_small.h"
+#include "ekf_large.h"
 #if ASLAM_HAVE_UKF
 #include "ukf_small.h"
 #endif
@@ -53,6 +54,11 @@ struct aslam_ctx
 #if ASLAM_HAVE_UKF
         UkfView ukf;
 #endif
+        // large-state path (n > 143): typed covariance buffers, one launch chain per callback
+        bool large = false;
+        LargeView<double> lv64 = {};
+        LargeView<float> lv32 = {};
+        int *skipped = nullptr;
 };
 
 namespace
@@ -65,6 +71,75 @@ template <typename T> int dev_alloc(aslam_ctx *c, T **p, size_t count, std::vect
         pool.push_back(q);
         c->hbm_bytes += (int64_t)(count * sizeof(T));
         *p = static_cast<T *>(q);
+        return ASLAM_OK;
+}
+
+/// copy a host n x n double matrix into filter `traj`'s P (padded stride NP, converted to the context's dtype)
+int upload_P(aslam_ctx *c, int traj, int n, const double *P)
+{
+        const size_t NP = (size_t)c->NP;
+        if (!c->large)
+        {
+                std::vector<double> v(NP * NP, 0.0);
+                for (int i = 0; i < n; ++i)
+                        std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
+                HIP_TRY(hipMemcpy(c->dv.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
+        }
+        else if (c->cfg.dtype == ASLAM_F32)
+        {
+                std::vector<float> v(NP * NP, 0.f);
+                for (int i = 0; i < n; ++i)
+                        for (int j = 0; j < n; ++j)
+                                v[(size_t)i * NP + j] = (float)P[(size_t)i * n + j];
+                HIP_TRY(hipMemcpy(c->lv32.P + traj * NP * NP, v.data(), sizeof(float) * NP * NP, hipMemcpyHostToDevice));
+        }
+        else
+        {
+                std::vector<double> v(NP * NP, 0.0);
+                for (int i = 0; i < n; ++i)
+                        std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
+                HIP_TRY(hipMemcpy(c->lv64.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
+        }
+        return ASLAM_OK;
+}
+
+int download_P(aslam_ctx *c, int traj, int n, double *P)
+{
+        const size_t NP = (size_t)c->NP;
+        if (c->large && c->cfg.dtype == ASLAM_F32)
+        {
+                std::vector<float> v((size_t)n * NP);
+                HIP_TRY(hipMemcpy(v.data(), c->lv32.P + traj * NP * NP, sizeof(float) * n * NP, hipMemcpyDeviceToHost));
+                for (int i = 0; i < n; ++i)
+                        for (int j = 0; j < n; ++j)
+                                P[(size_t)i * n + j] = (double)v[(size_t)i * NP + j];
+                return ASLAM_OK;
+        }
+        const double *src = c->large ? c->lv64.P : c->dv.P;
+        HIP_TRY(hipMemcpy2D(P, sizeof(double) * n, src + traj * NP * NP, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+/// new rows of P on growth: zero, with KP_LANDMARK_POSE on the diagonal (rows n_old .. n_new-1, full padded length)
+int grow_P_rows(aslam_ctx *c, int traj, int n_old, int n_new)
+{
+        const size_t NP = (size_t)c->NP;
+        for (int i = n_old; i < n_new; ++i)
+        {
+                if (c->large && c->cfg.dtype == ASLAM_F32)
+                {
+                        std::vector<float> row(NP, 0.f);
+                        row[i] = (float)KP_LANDMARK_POSE;
+                        HIP_TRY(hipMemcpy(c->lv32.P + traj * NP * NP + (size_t)i * NP, row.data(), sizeof(float) * NP, hipMemcpyHostToDevice));
+                }
+                else
+                {
+                        std::vector<double> row(NP, 0.0);
+                        row[i] = (double)KP_LANDMARK_POSE;
+                        double *dst = (c->large ? c->lv64.P : c->dv.P) + traj * NP * NP + (size_t)i * NP;
+                        HIP_TRY(hipMemcpy(dst, row.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
+                }
+        }
         return ASLAM_OK;
 }
 
@@ -83,6 +158,25 @@ int sync_ctx(aslam_ctx *c)
         return ASLAM_OK;
 }
 
+template <typename T> int init_P_large(aslam_ctx *c, LargeView<T> &lv)
+{
+        const size_t B = c->cfg.batch, NP = c->NP;
+        HIP_TRY(hipMemset(lv.P, 0, sizeof(T) * B * NP * NP));
+        HIP_TRY(hipMemset(lv.G, 0, sizeof(T) * B * NP * NP));
+        HIP_TRY(hipMemset(lv.S, 0, sizeof(T) * B * NP * NP));
+        std::vector<T> blk(3 * NP, (T)0);
+        for (int i = 0; i < 3; ++i)
+                blk[(size_t)i * NP + i] = (T)(double)KP_ROBOT_POSE;
+        for (size_t b = 0; b < B; ++b)
+                HIP_TRY(hipMemcpy(lv.P + b * NP * NP, blk.data(), sizeof(T) * blk.size(), hipMemcpyHostToDevice));
+        return ASLAM_OK;
+}
+
+int init_state_large(aslam_ctx *c)
+{
+        return c->cfg.dtype == ASLAM_F32 ? init_P_large(c, c->lv32) : init_P_large(c, c->lv64);
+}
+
 /// initialize() for the whole batch: ekf.cpp:49-71 / ukf.cpp:49-67
 int init_state(aslam_ctx *c)
 {
@@ -90,7 +184,8 @@ int init_state(aslam_ctx *c)
         DevView &d = c->dv;
         HIP_TRY(hipMemset(d.X, 0, sizeof(double) * B * NP));
         HIP_TRY(hipMemset(d.Z, 0, sizeof(double) * B * NP));
-        HIP_TRY(hipMemset(d.P, 0, sizeof(double) * (size_t)B * NP * NP));
+        if (!c->large)
+                HIP_TRY(hipMemset(d.P, 0, sizeof(double) * (size_t)B * NP * NP));
         HIP_TRY(hipMemset(d.status, 0, sizeof(uint32_t) * B));
         HIP_TRY(hipMemset(d.sens_n, 0, sizeof(int) * B));
         HIP_TRY(hipMemset(d.wait_n, 0, sizeof(int) * B));
@@ -104,6 +199,8 @@ int init_state(aslam_ctx *c)
         HIP_TRY(hipMemcpy(d.n, n.data(), sizeof(int) * B, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.flags, fl.data(), sizeof(int) * B, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.A, A.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice));
+        if (c->large)
+                return init_state_large(c);
         // P = Identity * KP_ROBOT_POSE on the 3 pose entries
         const double p0 = (double)KP_ROBOT_POSE;
         std::vector<double> blk((size_t)3 * NP, 0.0);
@@ -154,9 +251,67 @@ int launch_ukf(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, in
 }
 #endif
 
+/// one callback of the large-state EKF: front end + predict, G, S, blocked factorisation of [S; G; Y^T], P -= V V^T, X += V q
+template <typename T, int MODE>
+int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa,
+                   hipStream_t st)
+{
+        const int NP = c->NP, NB = NP / LB;
+        const size_t lds = LargeLds::bytes(NP);
+        auto fk = large_frontend_kernel<T, MODE>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int Bz = (MODE == MODE_STEP) ? 1 : c->cfg.batch;
+        (void)grid;
+        // in step mode the kernels index the filter through blockIdx: give them a view shifted to filter sa.traj
+        DevView dv = c->dv;
+        LargeView<T> v = lv;
+        int *skip = c->skipped;
+        if (MODE == MODE_STEP)
+        {
+                const size_t b = (size_t)sa.traj, np = (size_t)NP;
+                dv.X += b * np;
+                dv.Z += b * np;
+                dv.A += 2 * b;
+                dv.n += b;
+                dv.flags += b;
+                dv.status += b;
+                dv.sens_n += b;
+                dv.wait_n += b;
+                v.P += b * np * np;
+                v.G += b * np * np;
+                v.S += b * np * np;
+                v.Hc += b * (np / 2) * 4;
+                v.Y += b * np;
+                skip += b;
+                sa.traj = 0;
+        }
+        for (int s = 0; s < nsteps; ++s)
+        {
+                hipLaunchKernelGGL(fk, dim3(Bz), dim3(SMALL_WG), lds, st, dv, v, t0 + s, s, nsteps, poses, dims, sa, skip);
+                hipLaunchKernelGGL(large_build_G<T>, dim3(NP, Bz), dim3(256), 0, st, dv, v, skip);
+                hipLaunchKernelGGL(large_build_S<T>, dim3(NP, Bz), dim3(256), 0, st, dv, v, skip);
+                for (int k = 0; k < NB; ++k)
+                {
+                        hipLaunchKernelGGL(large_potrf_diag<T>, dim3(Bz), dim3(256), 0, st, dv, v, k, skip);
+                        hipLaunchKernelGGL(large_panel_solve<T>, dim3((2 * NP + 255) / 256, Bz), dim3(256), 0, st, dv, v, k, skip);
+                        if (k + 1 < NB)
+                                hipLaunchKernelGGL((large_gemm_nt<T, 0>), dim3(2 * NB - (k + 1), NB - (k + 1), Bz), dim3(256), 0, st, dv,
+                                                   v, k, skip);
+                }
+                hipLaunchKernelGGL((large_gemm_nt<T, 1>), dim3(NB, NB, Bz), dim3(256), 0, st, dv, v, 0, skip);
+                hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, Bz), dim3(256), 0, st, dv, v, s, nsteps, poses, dims,
+                                   skip);
+        }
+        HIP_TRY(hipGetLastError());
+        return ASLAM_OK;
+}
+
 template <int MODE>
 int launch(aslam_ctx *c, int grid, int64_t t0, int nsteps, double *poses, int32_t *dims, StepArgs sa, hipStream_t st)
 {
+        if (c->large)
+                return c->cfg.dtype == ASLAM_F32 ? launch_large_T<float, MODE>(c, c->lv32, grid, t0, nsteps, poses, dims, sa, st)
+                                                 : launch_large_T<double, MODE>(c, c->lv64, grid, t0, nsteps, poses, dims, sa, st);
         if (c->cfg.filter == ASLAM_EKF)
         {
                 switch (c->NT)
@@ -208,8 +363,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                 return fail(ASLAM_ERR_ARG, "filter must be ASLAM_EKF or ASLAM_UKF");
         if (cfg->batch < 1 || cfg->max_landmark_count < 4 || cfg->max_obs < 1 || cfg->max_wait < 1)
                 return fail(ASLAM_ERR_ARG, "batch, max_landmark_count, max_obs, max_wait must be positive");
-        if (cfg->dtype != ASLAM_F64)
-                return fail(ASLAM_ERR_UNSUPPORTED, "only ASLAM_F64 is implemented in this round");
+        if (cfg->dtype != ASLAM_F64 && cfg->dtype != ASLAM_F32)
+                return fail(ASLAM_ERR_ARG, "dtype must be ASLAM_F64 or ASLAM_F32");
         const int n_max = cfg->max_landmark_count - 1; // growth is refused at N >= MAX_LANDMARK_COUNT
         const int need = (n_max + 15) / 16;
         int NT = 0;
@@ -221,18 +376,30 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         break;
                 }
         }
-        if (!NT)
-                return fail(ASLAM_ERR_UNSUPPORTED, "state dimension above 144 needs the multi-workgroup path (not in this round)");
-        if (cfg->max_obs > SMALL_OBS_CAP)
-                return fail(ASLAM_ERR_UNSUPPORTED, "max_obs above 128 is not supported by the single-CU kernels");
-        if (cfg->max_wait > SMALL_WAIT_CAP)
-                return fail(ASLAM_ERR_UNSUPPORTED, "max_wait above 512 is not supported by the single-CU kernels");
+        const bool large = (NT == 0) || cfg->dtype == ASLAM_F32; // fp32 exists on the multi-workgroup path only
+        if (large)
+        {
+                if (cfg->filter != ASLAM_EKF)
+                        return fail(ASLAM_ERR_UNSUPPORTED, "the UKF is limited to state dimensions up to 143 (single-CU kernels) and fp64");
+                if (n_max + 1 > LARGE_NP_MAX)
+                        return fail(ASLAM_ERR_UNSUPPORTED, "state dimension above 1087 is not supported");
+                if (cfg->max_obs > LARGE_OBS_CAP || cfg->max_wait > LARGE_WAIT_CAP)
+                        return fail(ASLAM_ERR_UNSUPPORTED, "max_obs above 1024 / max_wait above 2048 are not supported");
+        }
+        else
+        {
+                if (cfg->max_obs > SMALL_OBS_CAP)
+                        return fail(ASLAM_ERR_UNSUPPORTED, "max_obs above 128 is not supported by the single-CU kernels");
+                if (cfg->max_wait > SMALL_WAIT_CAP)
+                        return fail(ASLAM_ERR_UNSUPPORTED, "max_wait above 512 is not supported by the single-CU kernels");
+        }
         HIP_TRY(hipSetDevice(cfg->device));
 
         aslam_ctx *c = new aslam_ctx();
         c->cfg = *cfg;
-        c->NT = NT;
-        c->NP = 16 * NT;
+        c->large = large;
+        c->NT = large ? 0 : NT;
+        c->NP = large ? ((n_max + 1 + LB - 1) / LB) * LB : 16 * NT; // the large path needs one spare row (Y^T rides in G)
         c->last_stream = nullptr;
         c->hbm_bytes = 0;
         std::memset(&c->dv, 0, sizeof(c->dv));
@@ -250,7 +417,30 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         };
         A_(dev_alloc(c, &d.X, B * NP, c->owned));
         A_(dev_alloc(c, &d.Z, B * NP, c->owned));
-        A_(dev_alloc(c, &d.P, B * NP * NP, c->owned));
+        if (!large)
+                A_(dev_alloc(c, &d.P, B * NP * NP, c->owned));
+        else
+        {
+                A_(dev_alloc(c, &c->skipped, B, c->owned));
+                if (cfg->dtype == ASLAM_F32)
+                {
+                        c->lv32.NP = c->NP;
+                        A_(dev_alloc(c, &c->lv32.P, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv32.G, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv32.S, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv32.Hc, B * (NP / 2) * 4, c->owned));
+                        A_(dev_alloc(c, &c->lv32.Y, B * NP, c->owned));
+                }
+                else
+                {
+                        c->lv64.NP = c->NP;
+                        A_(dev_alloc(c, &c->lv64.P, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv64.G, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv64.S, B * NP * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv64.Hc, B * (NP / 2) * 4, c->owned));
+                        A_(dev_alloc(c, &c->lv64.Y, B * NP, c->owned));
+                }
+        }
         A_(dev_alloc(c, &d.A, B * 2, c->owned));
         A_(dev_alloc(c, &d.n, B, c->owned));
         A_(dev_alloc(c, &d.flags, B, c->owned));
@@ -331,10 +521,9 @@ int aslam_set_state(aslam_ctx *c, int traj, int n, const double *X, const double
         }
         if (P)
         {
-                std::vector<double> v(NP * NP, 0.0);
-                for (int i = 0; i < n; ++i)
-                        std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
-                HIP_TRY(hipMemcpy(d.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
+                rc = upload_P(c, traj, n, P);
+                if (rc != ASLAM_OK)
+                        return rc;
         }
         const int fl = 0; // a filter whose state was handed over is past both init flags
         HIP_TRY(hipMemcpy(d.n + traj, &n, sizeof(int), hipMemcpyHostToDevice));
@@ -368,17 +557,10 @@ int aslam_grow(aslam_ctx *c, int traj, int n_new, const double *x_seed, const do
         const int k = n_new - n_old;
         HIP_TRY(hipMemcpy(d.X + traj * NP + n_old, x_seed, sizeof(double) * k, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.Z + traj * NP + n_old, z_seed, sizeof(double) * k, hipMemcpyHostToDevice));
-        // conservativeResizeLike(Identity * UKF_KP_LANDMARK_POSE): new rows/columns
-        double *Pg = d.P + traj * NP * NP;
-        std::vector<double> row(NP, 0.0);
-        for (int i = 0; i < n_old; ++i) // new columns of old rows are already zero padding: nothing to do
-                (void)i;
-        for (int i = n_old; i < n_new; ++i)
-        {
-                std::fill(row.begin(), row.end(), 0.0);
-                row[i] = (double)KP_LANDMARK_POSE;
-                HIP_TRY(hipMemcpy(Pg + (size_t)i * NP, row.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
-        }
+        // conservativeResizeLike(Identity * UKF_KP_LANDMARK_POSE): new rows (new columns of old rows are zero padding already)
+        rc = grow_P_rows(c, traj, n_old, n_new);
+        if (rc != ASLAM_OK)
+                return rc;
         HIP_TRY(hipMemcpy(d.n + traj, &n_new, sizeof(int), hipMemcpyHostToDevice));
         return ASLAM_OK;
 }
@@ -538,8 +720,7 @@ int aslam_get_state(aslam_ctx *c, int traj, double *X, double *Z, double *P)
         if (Z)
                 HIP_TRY(hipMemcpy(Z, d.Z + traj * NP, sizeof(double) * n, hipMemcpyDeviceToHost));
         if (P)
-                HIP_TRY(hipMemcpy2D(P, sizeof(double) * n, d.P + traj * NP * NP, sizeof(double) * NP, sizeof(double) * n, n,
-                                    hipMemcpyDeviceToHost));
+                return download_P(c, traj, n, P);
         return ASLAM_OK;
 }
 
@@ -682,7 +863,13 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
                 return fail(ASLAM_ERR_ARG, "null context");
         char buf[96];
         size_t lds = 0;
-        if (c->cfg.filter == ASLAM_EKF)
+        if (c->large)
+        {
+                std::snprintf(buf, sizeof(buf), "large_gemm_nt<%s,1> (+ %d-launch chain per callback)",
+                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 5 + 3 * (c->NP / LB));
+                lds = LargeLds::bytes(c->NP);
+        }
+        else if (c->cfg.filter == ASLAM_EKF)
         {
                 std::snprintf(buf, sizeof(buf), "ekf_small_kernel<%d,0>", c->NT);
                 lds = c->NT == 2 ? SmallLayout<2>::total : c->NT == 5 ? SmallLayout<5>::total : SmallLayout<9>::total;

@@ -26,14 +26,14 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
         unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
 
-        small_load<NP, MODE>(d, L, b, tid);
+        small_load<MODE>(d, L, b, tid, NP);
 
         for (int s = 0; s < nsteps; ++s)
         {
                 const int64_t t = t0 + s;
                 if (MODE == MODE_REPLAY)
                 {
-                        if (small_frontend<NP, true>(d, L, Pg, b, t, s, nsteps, poses_out, dims_out, tid))
+                        if (small_frontend<true, SMALL_OBS_CAP, SMALL_WAIT_CAP, NP / 2, double>(d, L, Pg, NP, b, t, s, nsteps, poses_out, dims_out, tid))
                                 continue;
                 }
                 else
@@ -237,6 +237,6 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 for (int i = 0; i < 12; ++i)
                         d.dbg[i] += stamp_acc[i];
 #endif
-        small_store<NP, MODE>(d, L, b, tid);
+        small_store<MODE>(d, L, b, tid, NP);
 }
 } // namespace aslam

@@ -856,7 +856,7 @@ template <int NT> __device__ __forceinline__ SmallLds small_carve(unsigned char 
 }
 
 /// Bring filter `b` from HBM into LDS (vectors, scalars, stored sensor message, wait-list).
-template <int NP, int MODE> __device__ __forceinline__ void small_load(const DevView &d, const SmallLds &L, int b, int tid)
+template <int MODE> __device__ __forceinline__ void small_load(const DevView &d, const SmallLds &L, int b, int tid, int NP)
 {
         SmallShared &sm = *L.sm;
         for (int i = tid; i < NP; i += SMALL_WG)
@@ -895,7 +895,7 @@ template <int NP, int MODE> __device__ __forceinline__ void small_load(const Dev
 }
 
 /// Write filter `b` back to HBM.
-template <int NP, int MODE> __device__ __forceinline__ void small_store(const DevView &d, const SmallLds &L, int b, int tid)
+template <int MODE> __device__ __forceinline__ void small_store(const DevView &d, const SmallLds &L, int b, int tid, int NP)
 {
         SmallShared &sm = *L.sm;
         __syncthreads();
@@ -938,8 +938,8 @@ template <int NP, int MODE> __device__ __forceinline__ void small_store(const De
 /// association, wait-list (ekf.cpp:217-253), promotion and growth (ekf.cpp:255-290), A (EKF), init_x.
 /// Returns true when cbOdom returned early (no sensor message yet): the caller skips slam().
 /// On return sm.vx / sm.az / sm.dt hold slam()'s binary32 arguments.
-template <int NP, bool IS_EKF>
-__device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds &L, double *Pg, int b, int64_t t, int s,
+template <bool IS_EKF, int OBS_CAP, int WAIT_CAP, int NEW_CAP, typename TP>
+__device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds &L, TP *Pg, int NP, int b, int64_t t, int s,
                                                int nsteps, double *poses_out, int32_t *dims_out, int tid)
 {
         SmallShared &sm = *L.sm;
@@ -961,10 +961,10 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 sm.dt = d.tr_dt[o];
                 sm.obs_new = d.tr_new[o];
                 int k = d.tr_nobs[o];
-                if (k > d.max_obs || k > SMALL_OBS_CAP)
+                if (k > d.max_obs || k > OBS_CAP)
                 {
                         sm.status |= 8u; // ASLAM_ST_OBS_OVERFLOW
-                        k = min(d.max_obs, SMALL_OBS_CAP);
+                        k = min(d.max_obs, OBS_CAP);
                 }
                 sm.nobs = k;
                 sm.any_miss = 0;
@@ -1101,7 +1101,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 // unassociated observations go through the wait-list in message order (they touch nothing the associated
                 // ones touch); counts only change here, so without a miss there is nothing to promote either
                 int wn = sm.wn;
-                const int wcap = min(d.max_wait, SMALL_WAIT_CAP);
+                const int wcap = min(d.max_wait, WAIT_CAP);
                 for (int j = 0; j < sm.sn; ++j)
                 {
                         if (n0 != 3 && sMd[j] < MIN_DIST_THRESH)
@@ -1148,7 +1148,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 {
                         if (sWc[i] == MIN_LANDMARK_OCC)
                         {
-                                if (nnew < NP / 2)
+                                if (nnew < NEW_CAP)
                                         sNew[nnew] = i;
                                 ++nnew;
                                 sWc[i] += 1;
@@ -1199,7 +1199,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 {
                         const int i = idx / n1, j = idx - i * n1;
                         if (i >= g0 || j >= g0)
-                                Pg[(size_t)i * NP + j] = (i == j) ? (double)KP_LANDMARK_POSE : 0.0;
+                                Pg[(size_t)i * NP + j] = (i == j) ? (TP)KP_LANDMARK_POSE : (TP)0;
                 }
         }
         if (sm.flags & FLAG_INIT_X)

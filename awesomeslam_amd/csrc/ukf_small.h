@@ -240,14 +240,14 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
         double *Kg = uv.K + (size_t)b * NP * NP;
         const double r_meas = (double)KR, q_proc = (double)KQ;
 
-        small_load<NP, MODE>(d, L, b, tid);
+        small_load<MODE>(d, L, b, tid, NP);
 
         for (int s = 0; s < nsteps; ++s)
         {
                 const int64_t t = t0 + s;
                 if (MODE == MODE_REPLAY)
                 {
-                        if (small_frontend<NP, false>(d, L, Pg, b, t, s, nsteps, poses_out, dims_out, tid))
+                        if (small_frontend<false, SMALL_OBS_CAP, SMALL_WAIT_CAP, NP / 2, double>(d, L, Pg, NP, b, t, s, nsteps, poses_out, dims_out, tid))
                                 continue;
                 }
                 else
@@ -577,6 +577,6 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 __syncthreads();
         }
 
-        small_store<NP, MODE>(d, L, b, tid);
+        small_store<MODE>(d, L, b, tid, NP);
 }
 } // namespace aslam

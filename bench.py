@@ -31,7 +31,10 @@ WORKLOADS = {
     "ekf64": ("ekf", 64, "configs[1]: EKF, 64 landmarks (n=131), fp64"),
     "ukf64": ("ukf", 64, "configs[2]: UKF, 64 landmarks (n=131), fp64"),
     "ekf8": ("ekf", 8, "configs[0] geometry on the GPU: EKF, 8 landmarks (n=19), fp64"),
+    "ekf512": ("ekf", 512, "configs[3]/[4]: EKF, 512 landmarks (n=1027), fp32 covariance, multi-workgroup launch chain"),
 }
+# fp32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_16x16x4_f32 at the vector rate)
+PEAK_F32_TFLOPS = 157.3
 # fp64 peak: 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz = 78.6 TFLOP/s, for v_fma_f64 and v_mfma_f64 alike
 # (= half of the 157.3 TFLOP/s FP32 row of MI355X_MICROARCH.md, which lists no fp64 row of its own)
 PEAK_F64_TFLOPS = 78.6
@@ -47,6 +50,24 @@ def cpu_baseline(kind, L, seed, prologue, sample):
     same workload: trajectory 0, `sample` steady-state callbacks after the warm-up prologue."""
     from oracle.c_oracle import CFilter
 
+    if L >= 256:
+        # a full-size callback of the as-coded algebra takes seconds at n = 1027: skip the 64-callback warm-up and time
+        # `sample` slam() calls on a synthetic state of the same dimension (same flops: the dense products do not
+        # depend on the values)
+        n = tg.full_dim(L)
+        rng = np.random.default_rng(seed)
+        X = np.concatenate([[0.3, -0.2, 0.4], (np.array([20.0, 0.0]) + 6 * rng.normal(size=(L, 2))).ravel()])
+        A = rng.normal(size=(n, n)) * 0.02
+        P = A @ A.T / n * 20 + np.eye(n) * 0.01
+        o = CFilter(kind, tg.dim_cap(L))
+        o.set_state(n, X, X.copy(), P, 0.07, -0.03)
+        t0 = time.perf_counter()
+        for _ in range(sample):
+            o.slam(0.2, 0.1, 1.0)
+        el = time.perf_counter() - t0
+        return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port",
+                "sample": f"{sample} slam() calls on a synthetic state of the same dimension N={n} (no warm-up: a callback takes "
+                          f"seconds); oracle/aslam_oracle.cpp (as-coded 18 n^3 dense algebra, fp64), g++ -O2, 1 thread, {el:.1f} s"}
     tr = tg.make_traces(L, prologue + sample, B=1, seed=seed)[0]
     o = CFilter(kind, tg.dim_cap(L))
     o.replay(tr.slice(0, prologue))
@@ -64,7 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ekf64", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=256, help="trajectories per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 256; 8 for ekf512)")
     ap.add_argument("--chunk", type=int, default=None,
                     help="callbacks per launch (= per bench step); default 500 (EKF) / 200 (UKF: the reference UKF only stays "
                          "positive definite for a few thousand callbacks at n = 131, DESIGN.md)")
@@ -82,8 +103,11 @@ def main():
 
     kind, L, cfg_name = WORKLOADS[args.workload]
     n_full = tg.full_dim(L)
+    large = args.workload == "ekf512"
     if args.chunk is None:
-        args.chunk = 200 if kind == "ukf" else 500
+        args.chunk = 20 if large else 200 if kind == "ukf" else 500
+    if args.batch is None:
+        args.batch = 8 if large else 256
     B, C, K, W = args.batch, args.chunk, args.steps, args.warmup
     prologue = 64  # callbacks: the 42-callback warm-up in which the state grows to n_full, rounded up
     T = prologue + (W + K) * C
@@ -92,7 +116,9 @@ def main():
     t_gen = time.time()
     tr = tg.make_traces(L, T, B=B, seed=args.seed, first_traj=rank * B)
     t_gen = time.time() - t_gen
-    core = Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(512, 2 * L + 64), device=local)
+    from awesomeslam_amd.core import F32, F64
+    core = Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
+                dtype=F32 if large else F64)
     core.set_trace(tr)
     stream = torch.cuda.current_stream().cuda_stream
     poses = torch.zeros((K, B, C, 3), dtype=torch.float64, device=dev)
@@ -134,6 +160,7 @@ def main():
         total_steps = world * B * C * K
         flops_launch = algorithmic_flops(kind, n_full) * B * C
         achieved = flops_launch / kernel_s / 1e12
+        peak = PEAK_F32_TFLOPS if large else PEAK_F64_TFLOPS
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
@@ -145,20 +172,20 @@ def main():
         out = {
             "metric": "EKF/UKF filter-steps/s @ N_landmarks", "value": total_steps / el, "unit": "filter-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if large else "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload} = {cfg_name}", "landmarks": L, "state_dim": n_full,
                        "trajectories_per_gpu": B, "callbacks_per_step": C, "parallelism": f"trajectory-sharded x{world}",
                        "kernel": info["name"], "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
                        "trace_gen_s": round(t_gen, 1)},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "kernel_ms": kernel_s * 1e3,
                          "note": "achieved = SURVEY 8(d) algorithmic flops/callback x callbacks x trajectories per launch / "
                                  "mean launch duration (HIP events on the launch stream); peak = fp64 FMA/MFMA rate"},
         }
         sample = args.cpu_sample
         if sample is None:
-            sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000}[args.workload]
+            sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000, "ekf512": 3}[args.workload]
         if world == 1 and sample > 0:
             out["cpu_baseline"] = cpu_baseline(kind, L, args.seed, prologue, sample)
         print(json.dumps(out))

@@ -44,10 +44,14 @@ def test_argument_errors_are_reported(built):
     assert b"filter" in lib.aslam_last_error()
     cfg = core.Config(0, 0, 30, 0, 8, 8, 0, 0)          # batch 0
     assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
-    cfg = core.Config(0, 1, 30, 1, 8, 8, 0, 0)          # fp32: not in this round
+    cfg = core.Config(1, 1, 30, 1, 8, 8, 0, 0)          # UKF in fp32: not available
     assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -3
-    cfg = core.Config(0, 0, 2000, 1, 8, 8, 0, 0)        # n > 144: multi-workgroup path, not in this round
+    cfg = core.Config(1, 0, 400, 1, 8, 8, 0, 0)         # UKF beyond the single-CU kernels (n > 143)
     assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -3
+    cfg = core.Config(0, 0, 2000, 1, 8, 8, 0, 0)        # n > 1087
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -3
+    cfg = core.Config(0, 7, 30, 1, 8, 8, 0, 0)          # unknown dtype
+    assert lib.aslam_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
 
 
 def test_no_cpu_fallback(built):
