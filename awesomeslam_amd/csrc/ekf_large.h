@@ -337,7 +337,6 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_S(DevVi
 template <typename T> __global__ __launch_bounds__(256) void large_potrf_diag(DevView d, LargeView<T> lv, int k, const int *skipped)
 {
         __shared__ T A[LB][LB + 1];
-        __shared__ T colv[LB];
         const int b = blockIdx.x;
         if (skipped[b])
                 return;
@@ -355,21 +354,20 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_diag(De
                 const T djj = A[j][j];
                 if (!(djj > (T)0))
                         bad = true;
-                const T dj = sqrt(djj);
-                if (tid < LB)
-                        colv[tid] = (tid > j) ? A[tid][j] / dj : (T)0;
+                const T rj = (T)1 / sqrt(djj);
+                // column j of L (every thread computes the entries it needs itself: one barrier per column)
+                const int m = LB - 1 - j; // active sub-block: rows/columns j+1 .. LB-1
+                for (int idx = tid; idx < m * m; idx += 256)
+                {
+                        const int i = j + 1 + idx / m, c = j + 1 + idx % m;
+                        if (i >= c)
+                                A[i][c] -= (A[i][j] * rj) * (A[c][j] * rj);
+                }
                 __syncthreads();
                 if (tid < LB && tid > j)
-                        A[tid][j] = colv[tid];
+                        A[tid][j] *= rj;
                 if (tid == 0)
-                        A[j][j] = dj;
-                // trailing update of the block: A[i][c] -= l_i l_c for j < c <= i
-                for (int idx = tid; idx < LB * LB; idx += 256)
-                {
-                        const int i = idx >> 6, c = idx & 63;
-                        if (c > j && i >= c)
-                                A[i][c] -= colv[i] * colv[c];
-                }
+                        A[j][j] = djj * rj;
                 __syncthreads();
         }
         for (int idx = tid; idx < LB * LB; idx += 256)
@@ -469,8 +467,8 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
         {
                 rt = blockIdx.x;
                 jt = blockIdx.y;
-                if (rt >= nb || jt >= nb)
-                        return;
+                if (rt >= nb || jt > rt)
+                        return; // V V^T is symmetric: lower tiles only, mirrored on store
                 kblocks = nb;
                 k0 = 0;
         }
@@ -534,8 +532,14 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
                         for (int r = 0; r < 4; ++r)
                         {
                                 const int row = wr + 16 * u + MM::row(lane, r), colc = jt * LB + wc + 16 * v + li;
-                                if (MODE == 0 || (rt * LB + row < n && colc < n)) // keep P's padding clean (row n of G is Y^T, not V)
+                                if (MODE == 0)
                                         Crow0[(size_t)row * NP + colc] -= acc[u][v][r];
+                                else if (rt * LB + row < n && colc < n) // keep P's padding clean (row n of G is Y^T, not V)
+                                {
+                                        Crow0[(size_t)row * NP + colc] -= acc[u][v][r];
+                                        if (jt < rt) // mirror into the upper triangle
+                                                lv.P[((size_t)b * NP + colc) * NP + rt * LB + row] -= acc[u][v][r];
+                                }
                         }
 }
 
