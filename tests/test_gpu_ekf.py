@@ -59,6 +59,7 @@ CASES = [
     ("L14-cap-refusal", 14, 100, dict(seed=26, stages=2), 30, None),  # refused landmarks keep filling the wait-list
     ("L20", 20, 300, dict(seed=27), None, None),                     # NT = 5 kernel
     ("L64", 64, 400, dict(seed=28), None, 150),                      # BASELINE config 2 geometry (n = 131)
+    ("L70-max", 70, 120, dict(seed=29), None, None),                 # n = 143: the largest state of the single-CU kernels
 ]
 
 

@@ -22,6 +22,7 @@ CASES = [
     ("L8-rewalk-randomdt", 8, 300, dict(seed=44, sensor_every=2, dt_mode="random"), 30, 50),
     ("L20", 20, 200, dict(seed=45), None, None),       # NT = 5 kernel
     ("L64", 64, 250, dict(seed=46), None, 100),        # BASELINE config 3 geometry (n = 131, 267 sigma points)
+    ("L70-max", 70, 80, dict(seed=47), None, None),    # n = 143, 291 sigma points: the largest state of the single-CU kernels
 ]
 
 
