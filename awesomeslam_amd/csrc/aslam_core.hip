@@ -292,11 +292,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 hipLaunchKernelGGL(large_build_S<T>, dim3(NP, Bz), dim3(256), 0, st, dv, v, skip);
                 for (int k = 0; k < NB; ++k)
                 {
+                        if (k > 0) // left-looking: bring block column k up to date with all earlier block columns at once
+                                hipLaunchKernelGGL((large_gemm_nt<T, 0>), dim3(2 * NB - k, 1, Bz), dim3(256), 0, st, dv, v, k, skip);
                         hipLaunchKernelGGL(large_potrf_diag<T>, dim3(Bz), dim3(256), 0, st, dv, v, k, skip);
                         hipLaunchKernelGGL(large_panel_solve<T>, dim3((2 * NP + 255) / 256, Bz), dim3(256), 0, st, dv, v, k, skip);
-                        if (k + 1 < NB)
-                                hipLaunchKernelGGL((large_gemm_nt<T, 0>), dim3(2 * NB - (k + 1), NB - (k + 1), Bz), dim3(256), 0, st, dv,
-                                                   v, k, skip);
                 }
                 hipLaunchKernelGGL((large_gemm_nt<T, 1>), dim3(NB, NB, Bz), dim3(256), 0, st, dv, v, 0, skip);
                 hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, Bz), dim3(256), 0, st, dv, v, s, nsteps, poses, dims,

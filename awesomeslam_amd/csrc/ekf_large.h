@@ -7,7 +7,7 @@
 //                    (ekf.cpp:117-134), Y = Z - h(X) (ekf.cpp:302-307)                               1 workgroup / filter
 //   large_build_G    G = P H^T             (H has <= 5 non-zeros per row: a column pass, ekf.cpp:301)
 //   large_build_S    S = H G + R           (row pass, ekf.cpp:300), Y^T appended to G as row n
-//   17 x { potrf_diag, panel_solve, gemm_nt }   blocked right-looking Cholesky S = L L^T of the STACKED matrix
+//   17 x { gemm_nt, potrf_diag, panel_solve }   blocked left-looking Cholesky S = L L^T of the STACKED matrix
 //                    [S; G; Y^T]: the same panel / trailing launches that factor S turn G into V = G L^-T and Y^T into
 //                    (L^-1 Y)^T, so  K = P H^T S^-1 = V L^-1  never needs a separate triangular solve
 //   gemm_nt          P <- P - V V^T        ( = (I - K H) P, ekf.cpp:310, since K H P = V V^T for symmetric P )
@@ -355,13 +355,16 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_diag(De
                 if (!(djj > (T)0))
                         bad = true;
                 const T rj = (T)1 / sqrt(djj);
-                // column j of L (every thread computes the entries it needs itself: one barrier per column)
-                const int m = LB - 1 - j; // active sub-block: rows/columns j+1 .. LB-1
-                for (int idx = tid; idx < m * m; idx += 256)
+                // rank-1 update of the active sub-block (every thread scales the two column entries it needs itself: one
+                // barrier per column); 16 x 16 thread grid striding over rows / columns j+1 .. 63
                 {
-                        const int i = j + 1 + idx / m, c = j + 1 + idx % m;
-                        if (i >= c)
-                                A[i][c] -= (A[i][j] * rj) * (A[c][j] * rj);
+                        const int ti = tid >> 4, tj = tid & 15;
+                        for (int i = j + 1 + ti; i < LB; i += 16)
+                        {
+                                const T li = A[i][j] * rj;
+                                for (int c = j + 1 + tj; c <= i; c += 16)
+                                        A[i][c] -= li * (A[c][j] * rj);
+                        }
                 }
                 __syncthreads();
                 if (tid < LB && tid > j)
@@ -421,11 +424,20 @@ template <typename T> __global__ __launch_bounds__(256) void large_panel_solve(D
 #pragma unroll
         for (int j = 0; j < LB; ++j)
         {
-                T acc = v[j];
+                // four independent partial sums: the dependent-FMA latency, not the issue rate, bounds a single chain
+                T a0 = v[j], a1 = (T)0, a2 = (T)0, a3 = (T)0;
 #pragma unroll
-                for (int c = 0; c < j; ++c)
-                        acc -= v[c] * Lk[j][c];
-                v[j] = acc * inv[j];
+                for (int c = 0; c < j; c += 4)
+                {
+                        a0 -= v[c] * Lk[j][c];
+                        if (c + 1 < j)
+                                a1 -= v[c + 1] * Lk[j][c + 1];
+                        if (c + 2 < j)
+                                a2 -= v[c + 2] * Lk[j][c + 2];
+                        if (c + 3 < j)
+                                a3 -= v[c + 3] * Lk[j][c + 3];
+                }
+                v[j] = ((a0 + a1) + (a2 + a3)) * inv[j];
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j)
@@ -434,8 +446,9 @@ template <typename T> __global__ __launch_bounds__(256) void large_panel_solve(D
 
 // ------------------------------------------------------------------------------------------------------------------
 /// C(tile r, tile j) -= A(tile r, kc..) B(tile j, kc..)^T over kblocks 64-wide column blocks starting at k0.
-///   MODE 0 (trailing update after panel k0): A = B source = stacked [S; G], C = stacked; tiles with j > k0, and for the
-///            S part only r >= j (lower); kblocks = 1.
+///   MODE 0 (left-looking update of block column k0 before it is factored): C(r, k0) -= sum_{k < k0} M(r, k) S(k0, k)^T for
+///            every stacked row tile r >= k0 (S part from the diagonal block down, then all of G); K = 64 k0, so every
+///            tile of the matrix is read-modify-written once per factorisation instead of once per earlier block column.
 ///   MODE 1 (P -= V V^T): A = B = G, C = P, all active tiles, kblocks = active blocks.
 /// grid (row tiles, column tiles, B), 256 threads = 4 waves, each wave a 32x32 quadrant of the 64x64 tile as 2x2 MFMA
 /// 16x16 tiles; operands staged through LDS 16 columns at a time.
@@ -443,8 +456,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv, int k0, const int *skipped)
 {
         typedef Mfma<T> MM;
-        __shared__ T As[LB][17];
-        __shared__ T Bs[LB][17];
+        constexpr int KC = (sizeof(T) == 4) ? 64 : 32; // columns staged per round: a whole K = 64 slab in fp32
+        __shared__ T As[LB][KC + 1];
+        __shared__ T Bs[LB][KC + 1];
         const int b = blockIdx.z;
         if (skipped[b])
                 return;
@@ -455,13 +469,12 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
         {
                 if (k0 >= nb)
                         return;
-                jt = k0 + 1 + blockIdx.y;
-                rt = k0 + 1 + blockIdx.x; // virtual row tile
-                if (jt >= nb || rt >= 2 * nb)
+                jt = k0;
+                rt = k0 + blockIdx.x; // virtual row tile: S rows from the diagonal block down, then all of G
+                if (rt >= 2 * nb)
                         return;
-                if (rt < nb && rt < jt)
-                        return; // upper triangle of S
-                kblocks = 1;
+                kblocks = k0;
+                k0 = 0;
         }
         else
         {
@@ -495,19 +508,27 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
 #pragma unroll
                 for (int v = 0; v < 2; ++v)
                         acc[u][v] = MM::zero();
-        const int lrow = tid >> 2, lc4 = (tid & 3) * 4; // 64 rows x 16 columns per stage, 4 consecutive columns per thread
-        for (int kc = 0; kc < kblocks * LB; kc += 16)
+        // stage: 64 rows x KC columns; a thread moves KC/4 consecutive columns of one row (all loads issued before use)
+        const int lrow = tid >> 2, lc0 = (tid & 3) * (KC / 4);
+        for (int kc = 0; kc < kblocks * LB; kc += KC)
         {
-                const int col = k0 * LB + kc + lc4;
+                const int col = k0 * LB + kc + lc0;
+                T ta[KC / 4], tb[KC / 4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < KC / 4; ++q)
                 {
-                        As[lrow][lc4 + q] = Arow0[(size_t)lrow * NP + col + q];
-                        Bs[lrow][lc4 + q] = Brow0[(size_t)lrow * NP + col + q];
+                        ta[q] = Arow0[(size_t)lrow * NP + col + q];
+                        tb[q] = Brow0[(size_t)lrow * NP + col + q];
+                }
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q)
+                {
+                        As[lrow][lc0 + q] = ta[q];
+                        Bs[lrow][lc0 + q] = tb[q];
                 }
                 __syncthreads();
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < KC / 4; ++s)
                 {
                         T av[2], bv[2];
 #pragma unroll

@@ -9,6 +9,8 @@
 #include <nav_msgs/Odometry.h>
 #include <ros/ros.h>
 
+#include <iostream>
+
 #include "../host/aslam_node.h"
 
 namespace
