@@ -297,7 +297,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         hipLaunchKernelGGL(large_potrf_diag<T>, dim3(Bz), dim3(256), 0, st, dv, v, k, skip);
                         hipLaunchKernelGGL(large_panel_solve<T>, dim3((2 * NP + 255) / 256, Bz), dim3(256), 0, st, dv, v, k, skip);
                 }
-                hipLaunchKernelGGL((large_gemm_nt<T, 1>), dim3(NB, NB, Bz), dim3(256), 0, st, dv, v, 0, skip);
+                {
+                        const int ntile = (NP + 127) / 128;
+                        hipLaunchKernelGGL(large_syrk<T>, dim3(8 * (ntile * (ntile + 1) / 2) * ((Bz + 7) / 8)), dim3(256), 0, st, dv, v, Bz, skip);
+                }
                 hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, Bz), dim3(256), 0, st, dv, v, s, nsteps, poses, dims,
                                    skip);
         }

@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
 {
         typedef Mfma<T> MM;
         constexpr int KC = (sizeof(T) == 4) ? 64 : 32; // columns staged per round: a whole K = 64 slab in fp32
-        __shared__ T As[LB][KC + 1];
-        __shared__ T Bs[LB][KC + 1];
+        __shared__ T As[LB][KC + 4]; // row stride = 4 mod 64 banks: the 16 rows x 4 k-values of an MFMA operand read hit 64 different banks
+        __shared__ T Bs[LB][KC + 4];
         const int b = blockIdx.z;
         if (skipped[b])
                 return;
@@ -562,6 +562,169 @@ __global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv,
                                                 lv.P[((size_t)b * NP + colc) * NP + rt * LB + row] -= acc[u][v][r];
                                 }
                         }
+}
+
+/// P -= V V^T (ekf.cpp:311 in the A-form, V = G after the panel solves) on 128x128 tiles: the kernel is bound by the
+/// operand traffic out of L2 (every row tile of V is read once per tile column), so the tile is as large as the
+/// accumulators allow: 4 waves, each a 64x64 quadrant = 4x4 MFMA 16x16 tiles (64 accumulator registers in fp32).  Lower
+/// tiles only, mirrored on store.  The next K slab is fetched into registers while the current one is multiplied.
+/// grid (8 * lower tiles * ceil(B/8)), 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, int nfilters, const int *skipped)
+{
+        typedef Mfma<T> MM;
+        constexpr int TB = 128;
+        constexpr int KC = (sizeof(T) == 4) ? 32 : 16;
+        constexpr int LDS_LD = (sizeof(T) == 4) ? KC + 4 : KC + 2; // fp32: stride = 4 mod 64 banks -> conflict-free operand reads
+        __shared__ T As[TB][LDS_LD];
+        __shared__ T Bs[TB][LDS_LD];
+        // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  All lower tiles of
+        // one filter are given ids that are equal mod 8, so the ~45 workgroups that share a filter's V run on one XCD and its
+        // row tiles are fetched into that L2 once instead of into all eight.
+        const int ntile = (lv.NP + TB - 1) / TB, nlow = ntile * (ntile + 1) / 2;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nlow) * 8 + (blockIdx.x & 7);
+        if (b >= nfilters || skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int na = large_blocks(n) * LB;
+        const int tl = slot % nlow;
+        int rt = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while ((rt + 1) * (rt + 2) / 2 <= tl)
+                ++rt;
+        while (rt * (rt + 1) / 2 > tl)
+                --rt;
+        const int jt = tl - rt * (rt + 1) / 2;
+        if (rt * TB >= na)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+        const T *G = lv.G + (size_t)b * NP * NP;
+        T *P = lv.P + (size_t)b * NP * NP;
+        // staging: 8 lanes cover one 128-byte row segment (KC elements) with 16-byte loads, so every wave-level load
+        // instruction fetches 8 whole cache lines; 4 passes of 32 rows
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int VW = 16 / sizeof(T);
+        static_assert(KC / VW == 8, "8 lanes per staged row");
+        const int lrow = tid >> 3, lc0 = (tid & 7) * VW;
+        // the last tile row may hang over the allocation: such rows read row na-1 instead (their products are never stored)
+        const T *Ap[4], *Bp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+                Ap[q] = G + (size_t)min(rt * TB + lrow + 32 * q, na - 1) * NP + lc0;
+                Bp[q] = G + (size_t)min(jt * TB + lrow + 32 * q, na - 1) * NP + lc0;
+        }
+        typename MM::acc_t acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        acc[u][v] = MM::zero();
+        vec_t ta[4], tb[4];
+        auto fetch = [&](int kc) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                        ta[q] = *reinterpret_cast<const vec_t *>(Ap[q] + kc);
+                        tb[q] = *reinterpret_cast<const vec_t *>(Bp[q] + kc);
+                }
+        };
+        // 16-row / 16-column subtiles of this wave's quadrant that hold at least one of the n valid rows / columns (n = 3 mod 128
+        // at full size: the last tile row is almost empty), and the upper quadrant of a diagonal tile is the mirror image of
+        // its lower one: neither is multiplied
+        const bool idle = (rt == jt && wc > wr);
+        const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
+        const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
+        const bool full = (nu == 4 && nv == 4);
+        fetch(0);
+        for (int kc = 0; kc < na; kc += KC)
+        {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                        *reinterpret_cast<vec_t *>(&As[lrow + 32 * q][lc0]) = ta[q];
+                        *reinterpret_cast<vec_t *>(&Bs[lrow + 32 * q][lc0]) = tb[q];
+                }
+                __syncthreads();
+                if (kc + KC < na)
+                        fetch(kc + KC);
+                if (full)
+                {
+#pragma unroll
+                        for (int s = 0; s < KC / 4; ++s)
+                        {
+                                T av[4], bv[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                {
+                                        av[u] = As[wr + 16 * u + li][lg + 4 * s];
+                                        bv[u] = Bs[wc + 16 * u + li][lg + 4 * s];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                        for (int v = 0; v < 4; ++v)
+                                                acc[u][v] = MM::mma(av[u], bv[v], acc[u][v]);
+                        }
+                }
+                else
+                {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                                if (u < nu)
+#pragma unroll
+                                        for (int v = 0; v < 4; ++v)
+                                                if (v < nv)
+#pragma unroll
+                                                        for (int s = 0; s < KC / 4; ++s)
+                                                                acc[u][v] = MM::mma(As[wr + 16 * u + li][lg + 4 * s], Bs[wc + 16 * v + li][lg + 4 * s],
+                                                                                    acc[u][v]);
+                }
+                __syncthreads();
+        }
+        if (idle)
+                return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                {
+                        const int col = jt * TB + wc + 16 * v + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                const int row = rt * TB + wr + 16 * u + MM::row(lane, r);
+                                if (row < n && col < n) // keep P's padding clean (row n of G is Y^T, not V)
+                                        P[(size_t)row * NP + col] -= acc[u][v][r];
+                        }
+                        if ((jt < rt || wc < wr) && col < n)
+                        {
+                                // mirror into the upper triangle.  fp32: a lane's four registers are four consecutive rows of
+                                // the tile = 16 contiguous bytes of the mirrored row: one 16-byte read-modify-write
+                                const int row0 = rt * TB + wr + 16 * u + MM::row(lane, 0);
+                                T *m = P + (size_t)col * NP + row0;
+                                if (sizeof(T) == 4 && row0 + 3 < n)
+                                {
+                                        typedef T vec4_t __attribute__((ext_vector_type(4)));
+                                        vec4_t x = *reinterpret_cast<vec4_t *>(m);
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                                x[r] -= acc[u][v][r];
+                                        *reinterpret_cast<vec4_t *>(m) = x;
+                                }
+                                else
+                                {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                        {
+                                                const int row = rt * TB + wr + 16 * u + MM::row(lane, r);
+                                                if (row < n)
+                                                        P[(size_t)col * NP + row] -= acc[u][v][r];
+                                        }
+                                }
+                        }
+                }
 }
 
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay

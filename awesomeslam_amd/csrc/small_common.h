@@ -637,6 +637,8 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
         }
         else if (wave == DW)
         {
+                // the diagonal wave is the critical path and shares its SIMD with two MFMA-heavy waves: let it win issue arbitration
+                __builtin_amdgcn_s_setprio(3);
                 bool ok = factor_diag_tile_fast(Lt, Dinv, lane);
                 __syncthreads();
                 for (int kb = 0; kb < nt; ++kb)
@@ -653,6 +655,7 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
+                __builtin_amdgcn_s_setprio(0);
         }
         else
         {

@@ -240,6 +240,10 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
         double *Kg = uv.K + (size_t)b * NP * NP;
         const double r_meas = (double)KR, q_proc = (double)KQ;
 
+#ifdef ASLAM_STAMPS
+        unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
         small_load<MODE>(d, L, b, tid, NP);
 
         for (int s = 0; s < nsteps; ++s)
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         __syncthreads();
                 }
 
+                ASLAM_STAMP(0);
                 // ================= slam(), ukf.cpp:260-392
                 const int n = sm.n;
                 const int nl = (n - 3) / 2;
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 __syncthreads();
                 cholesky_lookahead<NT>(Lt, Dinv, nt, tid, &sm.status);
 
+                ASLAM_STAMP(1);
                 // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)
                 auto Lkc = [&](int k, int c) -> double {
                         return (c <= k) ? Lt[tile_index(k >> 4, c >> 4) * TSZ + (k & 15) * TLD + (c & 15)] : 0.0;
@@ -355,7 +361,12 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 }
                 __syncthreads();
 
-                // ---- predicted mean, ukf.cpp:300-304 (same term order as the reference's loop over i)
+                // ---- predicted mean, ukf.cpp:300-304.  Pose rows: the weighted sum over all sigma points, in the reference's
+                // order.  Landmark rows are affine in the sigma points, the +- pairs cancel, and sum_i w_i x_i(k) = (sum_i w_i) X(k)
+                // exactly (the sum of the binary32 weights is not 1: that factor is part of the reference's arithmetic).
+                double wsum = w_0;
+                for (int i = 1; i < m; ++i)
+                        wsum += w_i;
                 for (int k = tid; k < NP; k += SMALL_WG)
                 {
                         double acc = 0.0;
@@ -365,145 +376,228 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                         acc += sW[i] * sXP[k * UL::MP + i];
                         }
                         else if (k < n)
-                        {
-                                acc += w_0 * sX[k];
-                                for (int c = 0; c < n + 2; ++c)
-                                        acc += w_i * (sX[k] + wsp * ((c < n) ? Lkc(k, c) : 0.0));
-                                for (int c = 0; c < n + 2; ++c)
-                                        acc += w_i * (sX[k] - wsp * ((c < n) ? Lkc(k, c) : 0.0));
-                        }
+                                acc = wsum * sX[k];
                         sXbar[k] = acc;
                 }
                 __syncthreads();
 
-                // ---- D = XsigPred - X, heading row wrapped (ukf.cpp:311-312), zero padding
-                for (int idx = tid; idx < 16 * nt * 16 * mt; idx += SMALL_WG)
+                ASLAM_STAMP(2);
+                // ---- D = XsigPred - X (ukf.cpp:311-312), Zsig = h(XsigPred) (ukf.cpp:322-326, common.h:78-90), Zpred (ukf.cpp:329-339),
+                // DZ = Zsig - Zpred (ukf.cpp:346-351), Zdiff (ukf.cpp:381-386) and the pose rows of P (ukf.cpp:307-319), one wave per row
+                // pair.  A sigma point moves landmark j (or the pose it is seen from) only if its column c of L is a pose column,
+                // the acceleration-noise column (c = n) or c <= 4 + 2 j (L is lower triangular); every other sigma point reproduces
+                // the centre point's reading bit for bit.  The wave evaluates h on the dense list of affected points only, keeps the
+                // readings in registers, reduces Zpred across lanes and writes each DZ entry once.
                 {
-                        const int k = idx / (16 * mt), i = idx - k * (16 * mt);
-                        double v = 0.0;
-                        if (k < n && i < m)
+                        const int lane = tid & 63;
+                        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                        constexpr int NWAVE = SMALL_WG / 64;
+                        constexpr int DCH = (2 * 16 * NT + 3 + 63) / 64; // chunks of the dense list (at most 2 n + 3 entries)
+                        for (int k = 16 * nt + tid; k < NP; k += SMALL_WG)
                         {
-                                if (k < 3)
+                                sY[k] = 0.0;
+                                sZpred[k] = 0.0;
+                        }
+                        auto wave_sum = [](double v) -> double {
+#pragma unroll
+                                for (int o = 1; o < 64; o <<= 1)
+                                        v += __shfl_xor(v, o);
+                                return v;
+                        };
+                        for (int r = wave; r < 3 + nl + (16 * nt - n); r += NWAVE)
+                        {
+                                if (r < 3)
                                 {
-                                        v = sXP[k * UL::MP + i] - sXbar[k];
-                                        if (k == 2)
-                                                v = (double)normalizeAngle((float)v);
+                                        // pose row k: D from the propagated poses, Zsig passes the pose through, 3 x 3 block of P
+                                        const int k = r;
+                                        const double zp = (k == 2) ? (double)normalizeAngle((float)sXbar[2]) : sXbar[k];
+                                        double acc[3] = {0.0, 0.0, 0.0};
+                                        for (int i = lane; i < 16 * mt; i += 64)
+                                        {
+                                                double dv[3] = {0.0, 0.0, 0.0}, z = 0.0;
+                                                if (i < m)
+                                                {
+                                                        dv[0] = sXP[i] - sXbar[0];
+                                                        dv[1] = sXP[UL::MP + i] - sXbar[1];
+                                                        dv[2] = (double)normalizeAngle((float)(sXP[2 * UL::MP + i] - sXbar[2]));
+                                                        z = sXP[k * UL::MP + i] - zp;
+                                                        if (k == 2)
+                                                                z = (double)normalizeAngle((float)z);
+                                                }
+                                                const double dk = (k == 0) ? dv[0] : (k == 1) ? dv[1] : dv[2];
+                                                Dg[(size_t)k * MP + i] = dk;
+                                                DZg[(size_t)k * MP + i] = z;
+                                                const double wd = sW[i] * dk;
+#pragma unroll
+                                                for (int a = 0; a < 3; ++a)
+                                                        acc[a] = fma(wd, dv[a], acc[a]);
+                                        }
+#pragma unroll
+                                        for (int a = 0; a < 3; ++a)
+                                                acc[a] = wave_sum(acc[a]);
+                                        if (lane == 0)
+                                        {
+#pragma unroll
+                                                for (int a = 0; a < 3; ++a)
+                                                        Pg[(size_t)k * NP + a] = acc[a] + ((a == k) ? q_proc : 0.0);
+                                                double zd = sZ[k] - zp;
+                                                if (k == 2)
+                                                        zd = (double)normalizeAngle((float)zd);
+                                                sY[k] = zd;
+                                                sZpred[k] = zp;
+                                        }
+                                }
+                                else if (r < 3 + nl)
+                                {
+                                        const int j = r - 3, ka = 3 + 2 * j, kb = 4 + 2 * j;
+                                        const double xba = sXbar[ka], xbb = sXbar[kb];
+                                        // rows ka, kb of D and their products with the three pose rows
+                                        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                                        for (int i = lane; i < 16 * mt; i += 64)
+                                        {
+                                                double da = 0.0, db = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0;
+                                                if (i < m)
+                                                {
+                                                        int c;
+                                                        double sg;
+                                                        col_of(i, c, sg);
+                                                        da = xsig(ka, c, sg) - xba;
+                                                        db = xsig(kb, c, sg) - xbb;
+                                                        p0 = sXP[i] - sXbar[0];
+                                                        p1 = sXP[UL::MP + i] - sXbar[1];
+                                                        p2 = (double)normalizeAngle((float)(sXP[2 * UL::MP + i] - sXbar[2]));
+                                                }
+                                                Dg[(size_t)ka * MP + i] = da;
+                                                Dg[(size_t)kb * MP + i] = db;
+                                                const double wa = sW[i] * da, wb = sW[i] * db;
+                                                acc[0] = fma(wa, p0, acc[0]);
+                                                acc[1] = fma(wa, p1, acc[1]);
+                                                acc[2] = fma(wa, p2, acc[2]);
+                                                acc[3] = fma(wb, p0, acc[3]);
+                                                acc[4] = fma(wb, p1, acc[4]);
+                                                acc[5] = fma(wb, p2, acc[5]);
+                                        }
+#pragma unroll
+                                        for (int a = 0; a < 6; ++a)
+                                                acc[a] = wave_sum(acc[a]);
+                                        if (lane < 6)
+                                        {
+                                                const int a = lane % 3, kk = (lane < 3) ? ka : kb;
+                                                double v = acc[0];
+#pragma unroll
+                                                for (int q = 1; q < 6; ++q)
+                                                        v = (lane == q) ? acc[q] : v;
+                                                Pg[(size_t)a * NP + kk] = v;
+                                                Pg[(size_t)kk * NP + a] = v; // mirror (the reference's two roundings differ in the last bit only)
+                                        }
+                                        // dense list of affected sigma points: a = 0 is the centre, then '+' columns 0..cmax and n, then '-'
+                                        const int cmax = min(4 + 2 * j, n - 1);
+                                        const int npl = cmax + 2;
+                                        const int na = 1 + 2 * npl;
+                                        double zr[DCH], zb[DCH];
+                                        int si[DCH];
+                                        double sr = 0.0, sb = 0.0;
+#pragma unroll
+                                        for (int q = 0; q < DCH; ++q)
+                                        {
+                                                const int a = lane + 64 * q;
+                                                zr[q] = 0.0;
+                                                zb[q] = 0.0;
+                                                si[q] = -1;
+                                                if (64 * q < na && a < na) // first test is wave-uniform: whole chunks are skipped
+                                                {
+                                                        int c = -1, i = 0;
+                                                        double sg = 0.0;
+                                                        if (a > 0)
+                                                        {
+                                                                int e = a - 1;
+                                                                const bool neg = e >= npl;
+                                                                if (neg)
+                                                                        e -= npl;
+                                                                c = (e <= cmax) ? e : n;
+                                                                sg = neg ? -1.0 : 1.0;
+                                                                i = neg ? c + n + 3 : c + 1;
+                                                        }
+                                                        const double lx = xsig(ka, c, sg), ly = xsig(kb, c, sg);
+                                                        const double ddx = lx - sXP[i], ddy = ly - sXP[UL::MP + i];
+                                                        zr[q] = sqrt(ddx * ddx + ddy * ddy);
+                                                        zb[q] = atan2(ddy, ddx) - sXP[2 * UL::MP + i];
+                                                        si[q] = i;
+                                                        sr = fma(sW[i], zr[q], sr);
+                                                        sb = fma(sW[i], zb[q], sb);
+                                                }
+                                        }
+                                        const double z0r = readfirstlane_f64(zr[0]), z0b = readfirstlane_f64(zb[0]);
+                                        const double wrest = w_i * (double)(m - na); // the unaffected points all carry w_i and the centre reading
+                                        const double zpr = fma(wrest, z0r, wave_sum(sr));
+                                        const double zpb = (double)normalizeAngle((float)fma(wrest, z0b, wave_sum(sb)));
+                                        // unaffected columns and padding first, then every affected point overwrites nothing: the sets are disjoint
+                                        const double ur = z0r - zpr, ub = (double)normalizeAngle((float)(z0b - zpb));
+                                        for (int i = lane; i < 16 * mt; i += 64)
+                                        {
+                                                int c;
+                                                double sg;
+                                                col_of(i, c, sg);
+                                                const bool affected = (i == 0) || c <= cmax || c == n;
+                                                if (!affected || i >= m)
+                                                {
+                                                        DZg[(size_t)ka * MP + i] = (i < m) ? ur : 0.0;
+                                                        DZg[(size_t)kb * MP + i] = (i < m) ? ub : 0.0;
+                                                }
+                                        }
+#pragma unroll
+                                        for (int q = 0; q < DCH; ++q)
+                                                if (si[q] >= 0)
+                                                {
+                                                        DZg[(size_t)ka * MP + si[q]] = zr[q] - zpr;
+                                                        DZg[(size_t)kb * MP + si[q]] = (double)normalizeAngle((float)(zb[q] - zpb));
+                                                }
+                                        if (lane == 0)
+                                        {
+                                                sY[ka] = sZ[ka] - zpr;
+                                                sY[kb] = (double)normalizeAngle((float)(sZ[kb] - zpb));
+                                                sZpred[ka] = zpr;
+                                                sZpred[kb] = zpb;
+                                        }
                                 }
                                 else
                                 {
-                                        int c;
-                                        double sg;
-                                        col_of(i, c, sg);
-                                        v = xsig(k, c, sg) - sXbar[k];
+                                        // padding rows n .. 16 nt - 1
+                                        const int k = n + (r - 3 - nl);
+                                        for (int i = lane; i < 16 * mt; i += 64)
+                                        {
+                                                Dg[(size_t)k * MP + i] = 0.0;
+                                                DZg[(size_t)k * MP + i] = 0.0;
+                                        }
+                                        if (lane == 0)
+                                        {
+                                                sY[k] = 0.0;
+                                                sZpred[k] = 0.0;
+                                        }
                                 }
                         }
-                        Dg[(size_t)k * MP + i] = v;
                 }
-                // ---- Zsig = h(XsigPred), ukf.cpp:322-326 / common.h:78-90: pose rows pass through
-                for (int idx = tid; idx < 3 * 16 * mt; idx += SMALL_WG)
-                {
-                        const int k = idx / (16 * mt), i = idx - k * (16 * mt);
-                        DZg[(size_t)k * MP + i] = (i < m) ? sXP[k * UL::MP + i] : 0.0;
-                }
-                for (int idx = tid; idx < nl * 16 * mt; idx += SMALL_WG)
-                {
-                        const int j = idx / (16 * mt), i = idx - j * (16 * mt);
-                        double zr = 0.0, zb = 0.0;
-                        if (i < m)
-                        {
-                                int c;
-                                double sg;
-                                col_of(i, c, sg);
-                                const double lx = xsig(3 + 2 * j, c, sg), ly = xsig(4 + 2 * j, c, sg);
-                                const double ddx = lx - sXP[i], ddy = ly - sXP[UL::MP + i];
-                                zr = sqrt(ddx * ddx + ddy * ddy);
-                                zb = atan2(ddy, ddx) - sXP[2 * UL::MP + i];
-                        }
-                        DZg[(size_t)(3 + 2 * j) * MP + i] = zr;
-                        DZg[(size_t)(4 + 2 * j) * MP + i] = zb;
-                }
-                for (int idx = tid; idx < (16 * nt - n) * 16 * mt; idx += SMALL_WG)
-                {
-                        const int k = n + idx / (16 * mt), i = idx % (16 * mt);
-                        DZg[(size_t)k * MP + i] = 0.0;
-                }
-                __syncthreads();
-
-                // ---- P = sum w d d^T + Q, ukf.cpp:307-319.  For two landmark entries a, b the sigma points are affine,
+                ASLAM_STAMP(3);
+                // ---- landmark block of P.  For two landmark entries a, b the sigma points are affine,
                 // d_i(a) = +-w L(a,c_i) + delta_a with delta_a = X(a) - Xbar(a) (not zero: the binary32 weights do not sum to 1),
                 // so the +- pairs cancel and, exactly,  sum_i w_i d_i(a) d_i(b) = (sum_i w_i) delta_a delta_b + 2 w_1 w^2 (L L^T)(a,b),
                 // with L L^T = P, the covariance that was just factored: an in-place scale + rank-1 term instead of a GEMM.
-                // Rows / columns of the three pose entries are nonlinear and are summed explicitly over the 2N+5 columns.
                 {
-                        double wsum = w_0;
-                        for (int i = 1; i < m; ++i)
-                                wsum += w_i;
                         const double cll = 2.0 * w_i * wsp * wsp;
-                        for (int idx = tid; idx < n * n; idx += SMALL_WG)
+                        for (int idx = tid; idx < (n - 3) * 16 * nt; idx += SMALL_WG)
                         {
-                                const int a = idx / n, bb = idx - a * n;
-                                if (a >= 3 && bb >= 3)
+                                const int a = 3 + idx / (16 * nt), bb = idx - (a - 3) * (16 * nt);
+                                if (bb >= 3 && bb < n)
                                 {
                                         const double da = sX[a] - sXbar[a], db = sX[bb] - sXbar[bb];
                                         Pg[(size_t)a * NP + bb] = fma(cll, Pg[(size_t)a * NP + bb], wsum * da * db);
                                 }
                         }
-                        for (int idx = tid; idx < 3 * n; idx += SMALL_WG)
-                        {
-                                const int a = idx / n, bb = idx - a * n;
-                                const double *ra = Dg + (size_t)a * MP, *rb = Dg + (size_t)bb * MP;
-                                double acc0 = 0.0, acc1 = 0.0;
-                                int i = 0;
-                                for (; i + 1 < m; i += 2)
-                                {
-                                        acc0 = fma(sW[i] * ra[i], rb[i], acc0);
-                                        acc1 = fma(sW[i + 1] * ra[i + 1], rb[i + 1], acc1);
-                                }
-                                if (i < m)
-                                        acc0 = fma(sW[i] * ra[i], rb[i], acc0);
-                                double v = acc0 + acc1;
-                                if (a == bb)
-                                        v += q_proc;
-                                Pg[(size_t)a * NP + bb] = v;
-                                if (bb >= 3)
-                                        Pg[(size_t)bb * NP + a] = v; // mirror (the reference's two roundings differ in the last bit only)
-                        }
                 }
                 __syncthreads();
+                ASLAM_STAMP(4);
 
-                // ---- Zpred = sum w Zsig, bearings wrapped (ukf.cpp:329-339); innovation Zdiff (ukf.cpp:381-386)
-                for (int k = tid; k < NP; k += SMALL_WG)
-                {
-                        double acc = 0.0;
-                        if (k < n)
-                        {
-                                const double *row = DZg + (size_t)k * MP;
-                                for (int i = 0; i < m; ++i)
-                                        acc += sW[i] * row[i];
-                                const bool wrapped = (k >= 2) && ((k & 1) == 0); // entries 2, 4, ..., N-1
-                                if (wrapped)
-                                        acc = (double)normalizeAngle((float)acc);
-                                double zd = sZ[k] - acc;
-                                if (wrapped)
-                                        zd = (double)normalizeAngle((float)zd);
-                                sY[k] = zd;
-                        }
-                        else
-                                sY[k] = 0.0;
-                        sZpred[k] = acc;
-                }
-                __syncthreads();
-                // ---- DZ = Zsig - Zpred, bearings wrapped (ukf.cpp:346-351), in place
-                for (int idx = tid; idx < n * m; idx += SMALL_WG)
-                {
-                        const int k = idx / m, i = idx - k * m;
-                        double v = DZg[(size_t)k * MP + i] - sZpred[k];
-                        if ((k >= 2) && ((k & 1) == 0))
-                                v = (double)normalizeAngle((float)v);
-                        DZg[(size_t)k * MP + i] = v;
-                }
-                __syncthreads();
-
+                ASLAM_STAMP(5);
                 // ---- Tc = sum w d dz^T (ukf.cpp:360-375) -> HBM
                 gemm_wabt<NT, GEMM_STORE>(Dg, DZg, MP, mt, sW, nt, Tcg, nullptr, 0.0, n, stage, tid);
                 // ---- S = sum w dz dz^T + R (ukf.cpp:342-357).  The central weight w_0 = (1-N)/3 is negative, so S can be
@@ -511,6 +605,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 // inverts S by LU (S.inverse(), ukf.cpp:378).  Here: S = S+ - z z^T with S+ = sum_{i>=1} w_i dz_i dz_i^T + R
                 // (symmetric positive definite -> LDS tiles -> tile Cholesky) and z = sqrt(-w_0) dz_0, and
                 //     Tc S^-1 = K+ + (K+ z) v^T / (1 - z^T v),   K+ = Tc S+^-1,  v = S+^-1 z      (Sherman-Morrison, exact).
+                ASLAM_STAMP(6);
                 const double zscale = sqrt(-w_0);
                 for (int k = tid; k < NP; k += SMALL_WG)
                         sZv[k] = (k < n) ? zscale * DZg[(size_t)k * MP] : 0.0;
@@ -520,8 +615,10 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 for (int j = tid; j < 16 * nt; j += SMALL_WG)
                         Tcg[(size_t)n * NP + j] = sZv[j];
                 __syncthreads();
+                ASLAM_STAMP(7);
                 // ---- K+ = Tc S+^-1 (and v^T = z^T S+^-1 in row n), u+ = K+ Zdiff: fused Cholesky + row-block solves
                 cholesky_solve_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, 1.0, tid, &sm.status);
+                ASLAM_STAMP(8);
                 for (int j = tid; j < NP; j += SMALL_WG)
                         sVv[j] = (j < 16 * nt) ? Kg[(size_t)n * NP + j] : 0.0;
                 for (int a = tid; a < NP; a += SMALL_WG)
@@ -561,12 +658,14 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                 sU[a] += sGv[a] * inv_den * vy;
                 }
                 __syncthreads();
+                ASLAM_STAMP(9);
                 // ---- X = X + K Zdiff (ukf.cpp:389)
                 for (int k = tid; k < n; k += SMALL_WG)
                         sX[k] = sXbar[k] + sU[k];
                 // ---- P = P - K S K^T (ukf.cpp:391): K S = Tc, so (K S) K^T = Tc K^T
                 gemm_wabt<NT, GEMM_SUBTRACT>(Tcg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid);
 
+                ASLAM_STAMP(10);
                 if (MODE == MODE_REPLAY)
                 {
                         if (tid < 3 && poses_out)
@@ -576,6 +675,11 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 }
                 __syncthreads();
         }
+#ifdef ASLAM_STAMPS
+        if (tid == 0 && blockIdx.x == 0 && d.dbg)
+                for (int i = 0; i < 12; ++i)
+                        d.dbg[i] += stamp_acc[i];
+#endif
 
         small_store<MODE>(d, L, b, tid, NP);
 }
