@@ -281,6 +281,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 v.G += b * np * np;
                 v.S += b * np * np;
                 v.Hc += b * (np / 2) * 4;
+                v.Linv += b * LB * LB;
                 v.Y += b * np;
                 skip += b;
                 sa.traj = 0;
@@ -288,14 +289,11 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         for (int s = 0; s < nsteps; ++s)
         {
                 hipLaunchKernelGGL(fk, dim3(Bz), dim3(SMALL_WG), lds, st, dv, v, t0 + s, s, nsteps, poses, dims, sa, skip);
-                hipLaunchKernelGGL(large_build_G<T>, dim3(NP, Bz), dim3(256), 0, st, dv, v, skip);
-                hipLaunchKernelGGL(large_build_S<T>, dim3(NP, Bz), dim3(256), 0, st, dv, v, skip);
+                hipLaunchKernelGGL(large_build_GS<T>, dim3(2 + NP / 2, Bz), dim3(256), 0, st, dv, v, skip);
                 for (int k = 0; k < NB; ++k)
                 {
-                        if (k > 0) // left-looking: bring block column k up to date with all earlier block columns at once
-                                hipLaunchKernelGGL((large_gemm_nt<T, 0>), dim3(2 * NB - k, 1, Bz), dim3(256), 0, st, dv, v, k, skip);
-                        hipLaunchKernelGGL(large_potrf_diag<T>, dim3(Bz), dim3(256), 0, st, dv, v, k, skip);
-                        hipLaunchKernelGGL(large_panel_solve<T>, dim3((2 * NP + 255) / 256, Bz), dim3(256), 0, st, dv, v, k, skip);
+                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(Bz), dim3(64), 0, st, dv, v, k, skip);
+                        hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, Bz), dim3(256), 0, st, dv, v, k, skip);
                 }
                 {
                         const int ntile = (NP + 127) / 128;
@@ -432,6 +430,7 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         A_(dev_alloc(c, &c->lv32.S, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv32.Hc, B * (NP / 2) * 4, c->owned));
                         A_(dev_alloc(c, &c->lv32.Y, B * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv32.Linv, B * LB * LB, c->owned));
                 }
                 else
                 {
@@ -441,6 +440,7 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         A_(dev_alloc(c, &c->lv64.S, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv64.Hc, B * (NP / 2) * 4, c->owned));
                         A_(dev_alloc(c, &c->lv64.Y, B * NP, c->owned));
+                        A_(dev_alloc(c, &c->lv64.Linv, B * LB * LB, c->owned));
                 }
         }
         A_(dev_alloc(c, &d.A, B * 2, c->owned));

@@ -5,12 +5,17 @@
 //   large_frontend   cbSensorLandmark + updateZandA (ekf.cpp:102-213, shared small_frontend code), predict
 //                    (X <- f(X), P <- A P A^T + Q with A = I + 2 entries, ekf.cpp:295-297), updateH coefficients
 //                    (ekf.cpp:117-134), Y = Z - h(X) (ekf.cpp:302-307)                               1 workgroup / filter
-//   large_build_G    G = P H^T             (H has <= 5 non-zeros per row: a column pass, ekf.cpp:301)
-//   large_build_S    S = H G + R           (row pass, ekf.cpp:300), Y^T appended to G as row n
-//   17 x { gemm_nt, potrf_diag, panel_solve }   blocked left-looking Cholesky S = L L^T of the STACKED matrix
-//                    [S; G; Y^T]: the same panel / trailing launches that factor S turn G into V = G L^-T and Y^T into
-//                    (L^-1 Y)^T, so  K = P H^T S^-1 = V L^-1  never needs a separate triangular solve
-//   gemm_nt          P <- P - V V^T        ( = (I - K H) P, ekf.cpp:310, since K H P = V V^T for symmetric P )
+//   large_build_GS   G = P H^T (H has <= 5 non-zeros per row, ekf.cpp:301) and S = H G + R (ekf.cpp:300) in one pass
+//                    over P; Y^T appended to G as row n
+//   17 x { potrf_inv, update_panel }   blocked Cholesky S = L L^T of the STACKED matrix [S; G; Y^T], 64-wide block
+//                    columns: a one-wave in-register factorisation of the diagonal block that also yields its inverse,
+//                    then ONE MFMA kernel per block column that brings the column up to date with all earlier ones
+//                    (left-looking, K = 64 k), eliminates it (X <- X Linv^T, a 64-deep product instead of a triangular
+//                    solve) and updates the diagonal blocks below (right-looking).  The same launches that factor S
+//                    turn G into V = G L^-T and Y^T into (L^-1 Y)^T, so K = P H^T S^-1 = V L^-1 never needs a
+//                    separate triangular solve
+//   large_syrk       P <- P - V V^T        ( = (I - K H) P, ekf.cpp:310, since K H P = V V^T for symmetric P ),
+//                    128x128 tiles, lower half mirrored, one filter's tiles on one XCD
 //   large_x_update   X <- X + V (L^-1 Y)   ( = X + K Y, ekf.cpp:309 )
 //
 // Unlike the single-CU kernel this path does not go through measurement coordinates: in fp32 the H / H^-1 change of
@@ -37,6 +42,7 @@ template <typename T> struct LargeView
         T *S;       // [B][NP][NP]  innovation covariance, then L (lower)
         double *Hc; // [B][NP/2][4] h00 h01 h10 h11 per landmark
         double *Y;  // [B][NP]
+        T *Linv;    // [B][LB][LB]  inverse of the diagonal block of L being eliminated
 };
 
 // ---- MFMA traits -------------------------------------------------------------------------------------------------
@@ -154,7 +160,12 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
         double *Yg = lv.Y + (size_t)b * NP;
 
+#ifdef ASLAM_STAMPS
+        unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
         small_load<MODE>(d, L, b, tid, NP);
+        ASLAM_STAMP(0);
         if (MODE == MODE_REPLAY)
         {
                 if (small_frontend<true, LARGE_OBS_CAP, LARGE_WAIT_CAP, LARGE_NP_MAX / 2, T>(d, L, Pg, NP, b, t, s, nsteps, poses_out,
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
                 }
                 __syncthreads();
         }
+        ASLAM_STAMP(1);
         if (tid == 0)
                 skipped[b] = 0;
         const int n = sm.n;
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
                 Yg[1] = sZ[1] - sX[1];
                 Yg[2] = (double)normalizeAngle((float)(sZ[2] - sX[2]));
         }
+        ASLAM_STAMP(2);
         // P <- A P A^T + Q (ekf.cpp:297), A = I except A(0,0), A(1,0): rows 0,1 then columns 0,1
         {
                 const T a00 = (T)sm.a00, a10 = (T)sm.a10, q = (T)(double)KQ;
@@ -239,104 +252,174 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
                 }
         }
         (void)Gg;
+        ASLAM_STAMP(3);
         small_store<MODE>(d, L, b, tid, NP);
+        ASLAM_STAMP(4);
+#ifdef ASLAM_STAMPS
+        if (tid == 0 && blockIdx.x == 0)
+                for (int i = 0; i < 12; ++i)
+                        d.dbg[i] += stamp_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-/// G = P H^T (one workgroup per matrix row; lanes over landmark pairs).  grid (NP, B).
-template <typename T> __global__ __launch_bounds__(256) void large_build_G(DevView d, LargeView<T> lv, const int *skipped)
+/// G = P H^T (ekf.cpp:301; H has <= 5 non-zeros per row) and S = H G + R (ekf.cpp:300) in one pass over P: a workgroup
+/// owns two consecutive rows (a landmark pair, or two padding rows; workgroup 0 the three pose rows), forms their G entries
+/// from the P rows it reads, re-forms the three pose rows of G it needs for H G (their P rows stay in L2), and writes G and S
+/// without G ever being read back.  Also copies Y^T into row n of G.  Threads run over landmark column pairs.
+/// grid (2 + NP/2, B), 256 threads.
+template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevView d, LargeView<T> lv, const int *skipped)
 {
-        const int b = blockIdx.y, a = blockIdx.x;
+        const int b = blockIdx.y;
         if (skipped[b])
                 return;
         const int n = d.n[b], NP = lv.NP;
         const int na = large_blocks(n) * LB;
-        if (a >= na)
-                return;
-        const T *prow = lv.P + ((size_t)b * NP + a) * NP;
-        T *grow = lv.G + ((size_t)b * NP + a) * NP;
-        const double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
         const int nl = (n - 3) / 2;
-        if (a >= n)
-        {
-                // padding rows (row n is filled with Y^T by large_build_S)
-                for (int c = threadIdx.x; c < na; c += 256)
-                        grow[c] = (T)0;
-                return;
-        }
-        const T t0 = prow[0], t1 = prow[1], t2 = prow[2];
-        if (threadIdx.x < 3)
-                grow[threadIdx.x] = prow[threadIdx.x];
-        for (int i = threadIdx.x; i < nl; i += 256)
-        {
-                const T h00 = (T)Hc[4 * i], h01 = (T)Hc[4 * i + 1], h10 = (T)Hc[4 * i + 2], h11 = (T)Hc[4 * i + 3];
-                const T ta = prow[3 + 2 * i], tb = prow[4 + 2 * i];
-                grow[3 + 2 * i] = h00 * t0 + h01 * t1 - h00 * ta - h01 * tb;
-                grow[4 + 2 * i] = h10 * t0 + h11 * t1 - t2 - h10 * ta - h11 * tb;
-        }
-        for (int c = n + threadIdx.x; c < na; c += 256)
-                grow[c] = (T)0;
-}
-
-/// S = H G + R (one workgroup per landmark pair / per pose or padding row; lanes over columns).  Also copies Y^T into
-/// row n of G.  grid (NP, B): blockIdx.x = output row.
-template <typename T> __global__ __launch_bounds__(256) void large_build_S(DevView d, LargeView<T> lv, const int *skipped)
-{
-        const int b = blockIdx.y, r = blockIdx.x;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        const int na = large_blocks(n) * LB;
-        if (r >= na)
-                return;
-        const T *G = lv.G + (size_t)b * NP * NP;
-        T *srow = lv.S + ((size_t)b * NP + r) * NP;
+        const T *P = lv.P + (size_t)b * NP * NP;
+        T *G = lv.G + (size_t)b * NP * NP;
+        T *S = lv.S + (size_t)b * NP * NP;
+        const double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
         const T rm = (T)(double)KR;
-        if (r >= n)
+        const int tid = threadIdx.x;
+        const bool pose = (blockIdx.x == 0);
+        const int r0 = pose ? 0 : 3 + 2 * ((int)blockIdx.x - 1); // first row of this workgroup
+        if (r0 >= na)
+                return;
+        if (!pose && r0 >= n)
         {
-                for (int c = threadIdx.x; c < na; c += 256)
-                        srow[c] = (c == r) ? (T)1 : (T)0;
-                if (r == n)
+                // padding rows r0, r0+1: G = 0 (row n: Y^T), S = identity
+                for (int rr = r0; rr < min(r0 + 2, na); ++rr)
                 {
-                        T *yrow = lv.G + ((size_t)b * NP + n) * NP;
+                        T *grow = G + (size_t)rr * NP, *srow = S + (size_t)rr * NP;
                         const double *Y = lv.Y + (size_t)b * NP;
-                        for (int c = threadIdx.x; c < na; c += 256)
-                                yrow[c] = (c < n) ? (T)Y[c] : (T)0;
+                        for (int c = tid; c < na; c += 256)
+                        {
+                                grow[c] = (rr == n && c < n) ? (T)Y[c] : (T)0;
+                                srow[c] = (c == rr) ? (T)1 : (T)0;
+                        }
                 }
                 return;
         }
-        if (r < 3)
+        // G(a, :) for one row a of P: columns 0..2 copy P, landmark column pair j mixes (t0, t1, t2, ta, tb) with H_j
+        const T *p0 = P, *p1 = P + NP, *p2 = P + 2 * (size_t)NP;
+        const T t00 = p0[0], t01 = p0[1], t02 = p0[2], t10 = p1[0], t11 = p1[1], t12 = p1[2], t20 = p2[0], t21 = p2[1], t22 = p2[2];
+        const T *pa = P + (size_t)r0 * NP, *pb = pa + NP; // landmark rows (unused by the pose workgroup)
+        T ta0 = 0, ta1 = 0, ta2 = 0, tb0 = 0, tb1 = 0, tb2 = 0, ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0;
+        if (!pose)
         {
-                for (int c = threadIdx.x; c < na; c += 256)
-                        srow[c] = (c < n) ? G[(size_t)r * NP + c] + (c == r ? rm : (T)0) : (T)0;
-                return;
+                ta0 = pa[0], ta1 = pa[1], ta2 = pa[2];
+                tb0 = pb[0], tb1 = pb[1], tb2 = pb[2];
+                const double *hr = Hc + 4 * ((r0 - 3) >> 1);
+                ha0 = (T)hr[0], ha1 = (T)hr[1], hb0 = (T)hr[2], hb1 = (T)hr[3]; // H rows r0 (range) and r0+1 (bearing)
         }
-        const int i = (r - 3) >> 1, odd = (r - 3) & 1;
-        const double *Hc = lv.Hc + ((size_t)b * (NP / 2) + i) * 4;
-        const T ha = (T)Hc[2 * odd], hb = (T)Hc[2 * odd + 1];
-        const T *g0 = G, *g1 = G + NP, *g2 = G + 2 * (size_t)NP;
-        const T *ga = G + (size_t)(3 + 2 * i) * NP, *gb = ga + NP;
-        for (int c = threadIdx.x; c < na; c += 256)
+        auto grow = [](T h00, T h01, T h10, T h11, T t0, T t1, T t2, T ta, T tb, T &ge, T &go) {
+                ge = h00 * t0 + h01 * t1 - h00 * ta - h01 * tb;
+                go = h10 * t0 + h11 * t1 - t2 - h10 * ta - h11 * tb;
+        };
+        // S(r, c) = (H G)(r, c) for landmark row r = r0 (+1): ha g0 + hb g1 [- g2] - ha ga - hb gb
+        auto srow = [](T ha, T hb, bool odd, T g0, T g1, T g2, T ga, T gb) -> T {
+                T v = ha * g0 + hb * g1;
+                if (odd)
+                        v -= g2;
+                return v - ha * ga - hb * gb;
+        };
+        // ---- pose columns 0..2 (G = P there)
+        if (tid < 3)
         {
-                T v = (T)0;
-                if (c < n)
+                const int c = tid;
+                const T g0 = p0[c], g1 = p1[c], g2 = p2[c];
+                if (pose)
                 {
-                        v = ha * g0[c] + hb * g1[c];
-                        if (odd)
-                                v -= g2[c];
-                        v = v - ha * ga[c] - hb * gb[c];
-                        if (c == r)
-                                v += rm;
+                        G[c] = g0, G[NP + c] = g1, G[2 * (size_t)NP + c] = g2;
+                        S[c] = g0 + (c == 0 ? rm : (T)0);
+                        S[NP + c] = g1 + (c == 1 ? rm : (T)0);
+                        S[2 * (size_t)NP + c] = g2 + (c == 2 ? rm : (T)0);
                 }
-                srow[c] = v;
+                else
+                {
+                        const T ga = pa[c], gb = pb[c];
+                        G[(size_t)r0 * NP + c] = ga;
+                        G[(size_t)(r0 + 1) * NP + c] = gb;
+                        S[(size_t)r0 * NP + c] = srow(ha0, ha1, false, g0, g1, g2, ga, gb);
+                        S[(size_t)(r0 + 1) * NP + c] = srow(hb0, hb1, true, g0, g1, g2, ga, gb);
+                }
+        }
+        // ---- landmark column pairs
+        for (int j = tid; j < nl; j += 256)
+        {
+                const int ce = 3 + 2 * j, co = ce + 1;
+                const T h00 = (T)Hc[4 * j], h01 = (T)Hc[4 * j + 1], h10 = (T)Hc[4 * j + 2], h11 = (T)Hc[4 * j + 3];
+                T g0e, g0o, g1e, g1o, g2e, g2o;
+                grow(h00, h01, h10, h11, t00, t01, t02, p0[ce], p0[co], g0e, g0o);
+                grow(h00, h01, h10, h11, t10, t11, t12, p1[ce], p1[co], g1e, g1o);
+                grow(h00, h01, h10, h11, t20, t21, t22, p2[ce], p2[co], g2e, g2o);
+                if (pose)
+                {
+                        G[ce] = g0e, G[co] = g0o;
+                        G[NP + ce] = g1e, G[NP + co] = g1o;
+                        G[2 * (size_t)NP + ce] = g2e, G[2 * (size_t)NP + co] = g2o;
+                        S[ce] = g0e, S[co] = g0o;
+                        S[NP + ce] = g1e, S[NP + co] = g1o;
+                        S[2 * (size_t)NP + ce] = g2e, S[2 * (size_t)NP + co] = g2o;
+                }
+                else
+                {
+                        T gae, gao, gbe, gbo;
+                        grow(h00, h01, h10, h11, ta0, ta1, ta2, pa[ce], pa[co], gae, gao);
+                        grow(h00, h01, h10, h11, tb0, tb1, tb2, pb[ce], pb[co], gbe, gbo);
+                        T *ga = G + (size_t)r0 * NP, *gb = ga + NP, *sa = S + (size_t)r0 * NP, *sb = sa + NP;
+                        ga[ce] = gae, ga[co] = gao;
+                        gb[ce] = gbe, gb[co] = gbo;
+                        T se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
+                        T ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
+                        if (ce == r0)
+                                se += rm; // R on the diagonal
+                        if (co == r0 + 1)
+                                uo += rm;
+                        sa[ce] = se, sa[co] = so;
+                        sb[ce] = ue, sb[co] = uo;
+                }
+        }
+        // ---- zero padding columns n .. na-1
+        const int nrows = pose ? 3 : 2;
+        for (int idx = tid; idx < nrows * (na - n); idx += 256)
+        {
+                const int rr = r0 + idx / (na - n), c = n + idx % (na - n);
+                G[(size_t)rr * NP + c] = (T)0;
+                S[(size_t)rr * NP + c] = (T)0;
         }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-/// Cholesky of the 64x64 diagonal block k of S, in place (lower; the strict upper part is zeroed).  grid (B), 256 threads.
-template <typename T> __global__ __launch_bounds__(256) void large_potrf_diag(DevView d, LargeView<T> lv, int k, const int *skipped)
+/// value of v in lane `lane` (a compile-time constant after unrolling), as a wave-uniform scalar
+__device__ __forceinline__ float lane_bcast(float v, int lane)
 {
-        __shared__ T A[LB][LB + 1];
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane)
+{
+        return readlane_f64(v, lane);
+}
+
+/// 1/sqrt(x): hardware seed + one Newton step (the pivots are the serial spine of the factorisation)
+__device__ __forceinline__ float rsqrt_fast(float x)
+{
+        const float y = __builtin_amdgcn_rsqf(x);
+        return y * fmaf(-0.5f * x * y, y, 1.5f);
+}
+__device__ __forceinline__ double rsqrt_fast(double x)
+{
+        return rsqrt_newton(x);
+}
+
+/// Cholesky of the 64x64 diagonal block k of S in place (lower; the strict upper part is zeroed) and the inverse of the
+/// factor -> Linv, by ONE wave with the block in registers: lane i holds row i, column entries of other rows are
+/// broadcast with v_readlane, so the 64 dependent column steps run without LDS or barriers.  The inverse (lane c carries
+/// column c of L^-1) lets the panel below the block be eliminated as a matrix product on the MFMA unit (X L^-T = X Linv^T).
+/// grid (B), 64 threads.
+template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevView d, LargeView<T> lv, int k, const int *skipped)
+{
         const int b = blockIdx.x;
         if (skipped[b])
                 return;
@@ -344,41 +427,61 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_diag(De
         if (k >= large_blocks(n))
                 return;
         T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
-        const int tid = threadIdx.x;
-        for (int idx = tid; idx < LB * LB; idx += 256)
-                A[idx >> 6][idx & 63] = S[(size_t)(idx >> 6) * NP + (idx & 63)];
-        __syncthreads();
+        T *Li = lv.Linv + (size_t)b * LB * LB;
+        const int lane = threadIdx.x;
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int VW = 16 / sizeof(T);
+        T a[LB];
+#pragma unroll
+        for (int c = 0; c < LB; c += VW)
+        {
+                const vec_t v = *reinterpret_cast<const vec_t *>(S + (size_t)lane * NP + c);
+#pragma unroll
+                for (int q = 0; q < VW; ++q)
+                        a[c + q] = v[q];
+        }
+        // s[r] = running sum of row r of column `lane` of L^-1 (forward substitution in outer-product form): once column j
+        // of L is final, x_j = s[j] / L(j,j) and s[c] -= L(c,j) x_j reuse the very multipliers L(c,j) the factorisation has
+        // just broadcast, so the inverse costs one extra FMA per broadcast and no second pass
+        T sres[LB];
+#pragma unroll
+        for (int c = 0; c < LB; ++c)
+                sres[c] = (lane == c) ? (T)1 : (T)0;
         bool bad = false;
+#pragma unroll
         for (int j = 0; j < LB; ++j)
         {
-                const T djj = A[j][j];
+                const T djj = lane_bcast(a[j], j);
                 if (!(djj > (T)0))
                         bad = true;
-                const T rj = (T)1 / sqrt(djj);
-                // rank-1 update of the active sub-block (every thread scales the two column entries it needs itself: one
-                // barrier per column); 16 x 16 thread grid striding over rows / columns j+1 .. 63
+                const T rj = rsqrt_fast(djj);
+                a[j] = (lane >= j) ? a[j] * rj : (T)0; // column j of L
+                const T xj = sres[j] * rj;             // (L^-1)(j, lane)
+                sres[j] = xj;
+#pragma unroll
+                for (int c = j + 1; c < LB; ++c)
                 {
-                        const int ti = tid >> 4, tj = tid & 15;
-                        for (int i = j + 1 + ti; i < LB; i += 16)
-                        {
-                                const T li = A[i][j] * rj;
-                                for (int c = j + 1 + tj; c <= i; c += 16)
-                                        A[i][c] -= li * (A[c][j] * rj);
-                        }
+                        const T lcj = lane_bcast(a[j], c);
+                        a[c] = fma(-a[j], lcj, a[c]); // A(i,c) -= L(i,j) L(c,j); entries above the diagonal are zeroed later
+                        sres[c] = fma(-lcj, xj, sres[c]);
+                        if (((c - j) & 7) == 0)
+                                __builtin_amdgcn_sched_barrier(0); // broadcasts in groups of 8: hoisting a whole column spills SGPRs
                 }
-                __syncthreads();
-                if (tid < LB && tid > j)
-                        A[tid][j] *= rj;
-                if (tid == 0)
-                        A[j][j] = djj * rj;
-                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
         }
-        for (int idx = tid; idx < LB * LB; idx += 256)
+#pragma unroll
+        for (int c = 0; c < LB; c += VW)
         {
-                const int i = idx >> 6, c = idx & 63;
-                S[(size_t)i * NP + c] = (c <= i) ? A[i][c] : (T)0;
+                vec_t v;
+#pragma unroll
+                for (int q = 0; q < VW; ++q)
+                        v[q] = a[c + q];
+                *reinterpret_cast<vec_t *>(S + (size_t)lane * NP + c) = v;
         }
-        if (bad && tid == 0)
+#pragma unroll
+        for (int r = 0; r < LB; ++r)
+                Li[r * LB + lane] = sres[r];
+        if (bad && lane == 0)
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
 }
 
@@ -389,179 +492,181 @@ template <typename T> __device__ __forceinline__ T *stacked_row(const LargeView<
         return (vr < na) ? lv.S + ((size_t)b * NP + vr) * NP : lv.G + ((size_t)b * NP + (vr - na)) * NP;
 }
 
-/// Panel k: every row below the diagonal block in S and every active row of G gets X <- X L_kk^-T on its 64 entries
-/// of block column k (one thread per row, L_kk broadcast from LDS).  grid (ceil(2*NP/256), B), 256 threads.
-template <typename T> __global__ __launch_bounds__(256) void large_panel_solve(DevView d, LargeView<T> lv, int k, const int *skipped)
-{
-        __shared__ T Lk[LB][LB + 1];
-        __shared__ T inv[LB];
-        const int b = blockIdx.y;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        const int nb = large_blocks(n), na = nb * LB;
-        if (k >= nb)
-                return;
-        const int first = (k + 1) * LB;       // first virtual row of the panel
-        const int rows = 2 * na - first;      // S rows below the block, then all of G
-        if ((int)blockIdx.x * 256 >= rows)
-                return;
-        const T *Sd = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
-        for (int idx = threadIdx.x; idx < LB * LB; idx += 256)
-                Lk[idx >> 6][idx & 63] = Sd[(size_t)(idx >> 6) * NP + (idx & 63)];
-        __syncthreads();
-        if (threadIdx.x < LB)
-                inv[threadIdx.x] = (T)1 / Lk[threadIdx.x][threadIdx.x];
-        __syncthreads();
-        const int lr = blockIdx.x * 256 + threadIdx.x;
-        if (lr >= rows)
-                return;
-        T *x = stacked_row(lv, b, na, first + lr) + k * LB;
-        T v[LB];
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-                v[j] = x[j];
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-        {
-                // four independent partial sums: the dependent-FMA latency, not the issue rate, bounds a single chain
-                T a0 = v[j], a1 = (T)0, a2 = (T)0, a3 = (T)0;
-#pragma unroll
-                for (int c = 0; c < j; c += 4)
-                {
-                        a0 -= v[c] * Lk[j][c];
-                        if (c + 1 < j)
-                                a1 -= v[c + 1] * Lk[j][c + 1];
-                        if (c + 2 < j)
-                                a2 -= v[c + 2] * Lk[j][c + 2];
-                        if (c + 3 < j)
-                                a3 -= v[c + 3] * Lk[j][c + 3];
-                }
-                v[j] = ((a0 + a1) + (a2 + a3)) * inv[j];
-        }
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-                x[j] = v[j];
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-/// C(tile r, tile j) -= A(tile r, kc..) B(tile j, kc..)^T over kblocks 64-wide column blocks starting at k0.
-///   MODE 0 (left-looking update of block column k0 before it is factored): C(r, k0) -= sum_{k < k0} M(r, k) S(k0, k)^T for
-///            every stacked row tile r >= k0 (S part from the diagonal block down, then all of G); K = 64 k0, so every
-///            tile of the matrix is read-modify-written once per factorisation instead of once per earlier block column.
-///   MODE 1 (P -= V V^T): A = B = G, C = P, all active tiles, kblocks = active blocks.
-/// grid (row tiles, column tiles, B), 256 threads = 4 waves, each wave a 32x32 quadrant of the 64x64 tile as 2x2 MFMA
-/// 16x16 tiles; operands staged through LDS 16 columns at a time.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void large_gemm_nt(DevView d, LargeView<T> lv, int k0, const int *skipped)
+/// Block column k0 of the stacked matrix M = [S; G; Y^T], for every 64-row block rt below the diagonal block:
+///   C  = M(rt, k0) - sum_{k < k0} M(rt, k) L(k0, k)^T      left-looking update, K = 64 k0, MFMA
+///   X  = C L(k0,k0)^-T = C Linv^T                           the panel "triangular solve" as a 64-deep MFMA product
+///   S(rt, rt) -= X X^T  (blocks of S only)                  the diagonal blocks are kept up to date right-looking, so
+///                                                           large_potrf_inv finds block k0+1 ready when this kernel ends
+/// One read-modify-write of every tile per factorisation.  A workgroup takes TWO consecutive 64-row blocks (a 128x64 tile:
+/// the block row of L is staged once for both, 128 MFMAs per wave between barriers); the two halves are addressed
+/// independently because the pair may straddle the S / G boundary.  4 waves, wave w = rows 32w..32w+31 of the tile as
+/// 2x4 MFMA 16x16 tiles.  The next K slab is fetched into registers while the current one is multiplied.
+/// grid (ceil((2 nb - k0 - 1) / 2), 1, B), 256 threads.
+template <typename T> __global__ __launch_bounds__(256) void large_update_panel(DevView d, LargeView<T> lv, int k0, const int *skipped)
 {
         typedef Mfma<T> MM;
-        constexpr int KC = (sizeof(T) == 4) ? 64 : 32; // columns staged per round: a whole K = 64 slab in fp32
-        __shared__ T As[LB][KC + 4]; // row stride = 4 mod 64 banks: the 16 rows x 4 k-values of an MFMA operand read hit 64 different banks
-        __shared__ T Bs[LB][KC + 4];
+        constexpr int KC = (sizeof(T) == 4) ? 64 : 32; // columns staged per round = 256 bytes of a row
+        constexpr int LD = KC + 4;
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int VW = 16 / sizeof(T);
+        static_assert(KC / VW == 16, "16 lanes per staged row");
+        __shared__ T As[2 * LB][LD];
+        __shared__ T Bs[LB][LD];
         const int b = blockIdx.z;
         if (skipped[b])
                 return;
         const int n = d.n[b], NP = lv.NP;
         const int nb = large_blocks(n), na = nb * LB;
-        int rt, jt, kblocks;
-        if (MODE == 0)
-        {
-                if (k0 >= nb)
-                        return;
-                jt = k0;
-                rt = k0 + blockIdx.x; // virtual row tile: S rows from the diagonal block down, then all of G
-                if (rt >= 2 * nb)
-                        return;
-                kblocks = k0;
-                k0 = 0;
-        }
-        else
-        {
-                rt = blockIdx.x;
-                jt = blockIdx.y;
-                if (rt >= nb || jt > rt)
-                        return; // V V^T is symmetric: lower tiles only, mirrored on store
-                kblocks = nb;
-                k0 = 0;
-        }
+        const int rt0 = k0 + 1 + 2 * blockIdx.x; // first virtual 64-row block: S rows below the diagonal block, then all of G
+        if (k0 >= nb || rt0 >= 2 * nb)
+                return;
+        const bool two = rt0 + 1 < 2 * nb; // the last workgroup may have a single block
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-        // source row pointers
-        const T *Arow0, *Brow0;
-        T *Crow0;
-        if (MODE == 0)
-        {
-                Arow0 = stacked_row(lv, b, na, rt * LB);
-                Brow0 = lv.S + ((size_t)b * NP + (size_t)jt * LB) * NP;
-                Crow0 = stacked_row(lv, b, na, rt * LB);
-        }
-        else
-        {
-                Arow0 = lv.G + ((size_t)b * NP + (size_t)rt * LB) * NP;
-                Brow0 = lv.G + ((size_t)b * NP + (size_t)jt * LB) * NP;
-                Crow0 = lv.P + ((size_t)b * NP + (size_t)rt * LB) * NP;
-        }
-        typename MM::acc_t acc[2][2];
+        const int half = wave >> 1;            // which 64-row block this wave's rows belong to
+        const int rt = rt0 + half;             // its virtual block index
+        const bool live = (half == 0) || two;  // wave-uniform
+        const int wr = 32 * wave;              // first tile row of the wave
+        const T *Brow = lv.S + ((size_t)b * NP + (size_t)k0 * LB) * NP; // block row k0 of L
+        typename MM::acc_t acc[2][4];
+        auto clear = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int v = 0; v < 2; ++v)
-                        acc[u][v] = MM::zero();
-        // stage: 64 rows x KC columns; a thread moves KC/4 consecutive columns of one row (all loads issued before use)
-        const int lrow = tid >> 2, lc0 = (tid & 3) * (KC / 4);
-        for (int kc = 0; kc < kblocks * LB; kc += KC)
-        {
-                const int col = k0 * LB + kc + lc0;
-                T ta[KC / 4], tb[KC / 4];
-#pragma unroll
-                for (int q = 0; q < KC / 4; ++q)
-                {
-                        ta[q] = Arow0[(size_t)lrow * NP + col + q];
-                        tb[q] = Brow0[(size_t)lrow * NP + col + q];
-                }
-#pragma unroll
-                for (int q = 0; q < KC / 4; ++q)
-                {
-                        As[lrow][lc0 + q] = ta[q];
-                        Bs[lrow][lc0 + q] = tb[q];
-                }
-                __syncthreads();
+                        for (int v = 0; v < 4; ++v)
+                                acc[u][v] = MM::zero();
+        };
+        clear();
+        // acc += As(rows of this wave) * Bsrc(rows vb .. vb+63)^T over one staged slab
+        auto multiply = [&](const T(*Bsrc)[LD], int vb) {
 #pragma unroll
                 for (int s = 0; s < KC / 4; ++s)
                 {
-                        T av[2], bv[2];
+                        T av[2], bv[4];
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
-                        {
                                 av[u] = As[wr + 16 * u + li][lg + 4 * s];
-                                bv[u] = Bs[wc + 16 * u + li][lg + 4 * s];
-                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                                bv[v] = Bsrc[vb + 16 * v + li][lg + 4 * s];
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
-                                for (int v = 0; v < 2; ++v)
+                                for (int v = 0; v < 4; ++v)
                                         acc[u][v] = MM::mma(av[u], bv[v], acc[u][v]);
                 }
+        };
+        // ---- left-looking update.  Staging: 16 lanes cover the 256-byte row segment of a slab with 16-byte loads.
+        const int lrow = tid >> 4, lc0 = (tid & 15) * VW;
+        const T *Ap[8], *Bp[4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+        {
+                const int r = lrow + 16 * q;                           // tile row 0..127
+                const int vr = (rt0 + ((r >> 6) & (two ? 1 : 0))) * LB + (r & 63); // a missing second block re-reads the first
+                Ap[q] = stacked_row(lv, b, na, vr) + lc0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+                Bp[q] = Brow + (size_t)(lrow + 16 * q) * NP + lc0;
+        vec_t ta[8], tb[4];
+        auto fetch = [&](int kc) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                        ta[q] = *reinterpret_cast<const vec_t *>(Ap[q] + kc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                        tb[q] = *reinterpret_cast<const vec_t *>(Bp[q] + kc);
+        };
+        const int Kend = k0 * LB;
+        if (Kend > 0)
+                fetch(0);
+        for (int kc = 0; kc < Kend; kc += KC)
+        {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                        *reinterpret_cast<vec_t *>(&As[lrow + 16 * q][lc0]) = ta[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<vec_t *>(&Bs[lrow + 16 * q][lc0]) = tb[q];
+                __syncthreads();
+                if (kc + KC < Kend)
+                        fetch(kc + KC);
+                multiply(Bs, 0);
                 __syncthreads();
         }
+        // ---- C = M(rt, k0) - acc (kept in registers in the accumulator layout)
+        T *Mrow = stacked_row(lv, b, na, (live ? rt : rt0) * LB) + (size_t)(wr & 63) * NP; // first row of this wave
+        T *Ctile = Mrow + (size_t)k0 * LB;
+        typename MM::acc_t cr[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int v = 0; v < 2; ++v)
+                for (int v = 0; v < 4; ++v)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                        {
-                                const int row = wr + 16 * u + MM::row(lane, r), colc = jt * LB + wc + 16 * v + li;
-                                if (MODE == 0)
-                                        Crow0[(size_t)row * NP + colc] -= acc[u][v][r];
-                                else if (rt * LB + row < n && colc < n) // keep P's padding clean (row n of G is Y^T, not V)
+                                cr[u][v][r] = Ctile[(size_t)(16 * u + MM::row(lane, r)) * NP + 16 * v + li] - acc[u][v][r];
+        clear();
+        // ---- X = C Linv^T, K = 64 in slabs of KC: stage C (from registers) and Linv (row c of Linv = column c of the product)
+        const T *Li = lv.Linv + (size_t)b * LB * LB;
+        auto stage_regs = [&](const typename MM::acc_t(&src)[2][4], int kh) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
                                 {
-                                        Crow0[(size_t)row * NP + colc] -= acc[u][v][r];
-                                        if (jt < rt) // mirror into the upper triangle
-                                                lv.P[((size_t)b * NP + colc) * NP + rt * LB + row] -= acc[u][v][r];
+                                        const int col = 16 * v + li;
+                                        if (col / KC == kh)
+                                                As[wr + 16 * u + MM::row(lane, r)][col % KC] = src[u][v][r];
                                 }
-                        }
+        };
+        for (int kh = 0; kh < LB / KC; ++kh)
+        {
+                stage_regs(cr, kh);
+                for (int idx = tid; idx < LB * KC; idx += 256)
+                        Bs[idx / KC][idx % KC] = Li[(idx / KC) * LB + kh * KC + (idx % KC)];
+                __syncthreads();
+                multiply(Bs, 0);
+                __syncthreads();
+        }
+        if (live)
+        {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        Ctile[(size_t)(16 * u + MM::row(lane, r)) * NP + 16 * v + li] = acc[u][v][r];
+        }
+        if (rt0 >= nb)
+                return; // only blocks of G in this workgroup: done (workgroup-uniform)
+        // ---- S(rt, rt) -= X X^T for the blocks of S: this wave's 32 rows of X against the 64 rows of its own block
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        cr[u][v] = acc[u][v];
+        clear();
+        for (int kh = 0; kh < LB / KC; ++kh)
+        {
+                stage_regs(cr, kh);
+                __syncthreads();
+                multiply(As, 64 * half);
+                __syncthreads();
+        }
+        if (live && rt < nb)
+        {
+                T *Dtile = Mrow + (size_t)rt * LB;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        Dtile[(size_t)(16 * u + MM::row(lane, r)) * NP + 16 * v + li] -= acc[u][v][r];
+        }
 }
 
 /// P -= V V^T (ekf.cpp:311 in the A-form, V = G after the panel solves) on 128x128 tiles: the kernel is bound by the

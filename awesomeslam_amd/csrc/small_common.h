@@ -84,6 +84,22 @@ struct DevView
 #define ASLAM_STAMP(i)
 #endif
 
+#ifdef ASLAM_FE_STAMPS
+#define FE_STAMP(i)                                                                                                    \
+        do                                                                                                             \
+        {                                                                                                              \
+                __syncthreads();                                                                                       \
+                if (tid == 0 && blockIdx.x == 0)                                                                       \
+                {                                                                                                      \
+                        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
+                        d.dbg[i] += now_ - fe_last;                                                                    \
+                        fe_last = now_;                                                                                \
+                }                                                                                                      \
+        } while (0)
+#else
+#define FE_STAMP(i)
+#endif
+
 struct StepArgs
 {
         int traj;
@@ -951,7 +967,9 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         int *const sCid = L.sCid, *const sNew = L.sNew;
         float *const sWr = L.sWr, *const sWb = L.sWb, *const sWx = L.sWx, *const sWy = L.sWy;
         uint32_t *const sWc = L.sWc;
-        (void)0;
+#ifdef ASLAM_FE_STAMPS
+        unsigned long long fe_last = __builtin_amdgcn_s_memtime();
+#endif
         // ================= message intake
         if (tid == 0)
         {
@@ -1000,6 +1018,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         dims_out[(size_t)b * nsteps + s] = sm.n;
                 return true;
         }
+        FE_STAMP(5); // intake + sensor copy
         // ================= updateZandA, ekf.cpp:137-213
         if (tid == 0)
         {
@@ -1025,24 +1044,49 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 L.sLm[2 * k + 1] = (float)sX[4 + 2 * k];
         }
         __syncthreads();
-        // nearest mapped landmark of every observation (ekf.cpp:159-173).  Four threads per observation scan a quarter
-        // of the landmarks each, in index order with the reference's strict `dist < mindist`; the quarters are then
-        // combined in order, so ties, infinities and NaNs resolve exactly as in the sequential scan.
-        const int chunk = (nl + 3) >> 2;
+        FE_STAMP(6); // toPoint + landmark narrowing
+        // nearest mapped landmark of every observation (ekf.cpp:159-173).  Four threads per observation scan the landmarks
+        // k = c, c+4, c+8, ... each (adjacent LDS words across the four: no bank conflicts), in index order with the
+        // reference's strict `dist < mindist`.  sqrtf is correctly rounded, hence monotonic: a candidate whose squared
+        // distance is not below the squared distance of the current best cannot have a smaller distance, so the root is only
+        // taken for the few that pass that test -- the comparison that decides is still the reference's, on the rooted values.
+        // The four partial results are then combined (smallest distance, smallest index among equals = first in index order),
+        // so ties, infinities and NaNs resolve exactly as in the sequential scan.
         for (int idx = tid; idx < 4 * sm.sn; idx += SMALL_WG)
         {
                 const int j = idx >> 2, c = idx & 3;
-                const int k0 = c * chunk, k1 = min(nl, k0 + chunk);
                 const float ox = sPx[j], oy = sPy[j];
-                float bd = __builtin_inff();
+                float bd = __builtin_inff(), bd2 = __builtin_inff();
                 int bk = -1;
-                for (int k = k0; k < k1; ++k)
+                const float2 *lm = reinterpret_cast<const float2 *>(L.sLm);
+                // eulerDistance, tools.h:53-59.  The reference subtracts in double and narrows; for two binary32 inputs that is the
+                // binary32 difference bit for bit (the double difference is exact unless the exponents are more than 28 apart, and
+                // then both round to the larger operand), without six slow f64 instructions
+                int k = c;
+                if (c == 0 && nl > 0) // mindist starts as the distance to landmark 0, whatever it is
                 {
-                        const float dd = eulerDistance(ox, oy, L.sLm[2 * k], L.sLm[2 * k + 1]);
-                        if (k == 0 || dd < bd) // mindist starts as the distance to landmark 0, whatever it is
+                        const float2 p = lm[0];
+                        const float dx = ox - p.x, dy = oy - p.y;
+                        bd2 = dx * dx + dy * dy;
+                        bd = sqrtf(bd2);
+                        bk = 0;
+                        k = 4;
+                }
+#pragma unroll 4
+                for (; k < nl; k += 4)
+                {
+                        const float2 p = lm[k];
+                        const float dx = ox - p.x, dy = oy - p.y;
+                        const float d2 = dx * dx + dy * dy;
+                        if (d2 < bd2)
                         {
-                                bd = dd;
-                                bk = k;
+                                const float dd = sqrtf(d2);
+                                if (dd < bd)
+                                {
+                                        bd = dd;
+                                        bd2 = d2;
+                                        bk = k;
+                                }
                         }
                 }
                 L.sPd[idx] = bd;
@@ -1050,6 +1094,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         }
         for (int k = tid; k < nl; k += SMALL_WG)
                 sNew[k] = -1; // last observation associated with landmark k
+        FE_STAMP(7); // scan
         __syncthreads();
         for (int j = tid; j < sm.sn; j += SMALL_WG)
         {
@@ -1059,10 +1104,11 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 for (int c = 1; c < 4; ++c)
                 {
                         const float od = L.sPd[4 * j + c];
-                        if (L.sPi[4 * j + c] >= 0 && od < bd)
+                        const int ok = L.sPi[4 * j + c];
+                        if (ok >= 0 && (od < bd || (od == bd && ok < bk)))
                         {
                                 bd = od;
-                                bk = L.sPi[4 * j + c];
+                                bk = ok;
                         }
                 }
                 if (nl == 0)
@@ -1087,6 +1133,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         sZ[4 + sCid[j]] = (double)sSb[j];
                 }
         }
+        FE_STAMP(8); // combine + Z
         if (sm.any_miss)
         {
                 // wait-list entries re-projected from the current pose (ekf.cpp:229,233)
@@ -1180,6 +1227,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         }
                 }
         }
+        FE_STAMP(9); // wait-list walk
         if (tid == 0)
         {
                 // Update A, ekf.cpp:206-212 (the UKF node has no A)
@@ -1194,6 +1242,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 sm.az = (float)sm.twz;
         }
         __syncthreads();
+        FE_STAMP(10); // A
         if (sm.grew)
         {
                 // conservativeResizeLike(Identity * UKF_KP_LANDMARK_POSE), ekf.cpp:277

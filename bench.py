@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ekf64", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 256; 128 for ekf512)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 256)")
     ap.add_argument("--chunk", type=int, default=None,
                     help="callbacks per launch (= per bench step); default 500 (EKF) / 200 (UKF: the reference UKF only stays "
                          "positive definite for a few thousand callbacks at n = 131, DESIGN.md)")
@@ -107,7 +107,7 @@ def main():
     if args.chunk is None:
         args.chunk = 20 if large else 200 if kind == "ukf" else 500
     if args.batch is None:
-        args.batch = 128 if large else 256
+        args.batch = 256
     B, C, K, W = args.batch, args.chunk, args.steps, args.warmup
     prologue = 64  # callbacks: the 42-callback warm-up in which the state grows to n_full, rounded up
     T = prologue + (W + K) * C
