@@ -59,6 +59,12 @@ struct aslam_ctx
         LargeView<double> lv64 = {};
         LargeView<float> lv32 = {};
         int *skipped = nullptr;
+        // replay splits the batch into groups that run the launch chain side by side on separate streams: the latency-bound
+        // launches of one group (one-wave diagonal factorisations, the front end, short-K panels) then overlap the GEMMs of
+        // the others
+        static constexpr int LARGE_GROUPS = 4;
+        hipStream_t aux[LARGE_GROUPS - 1] = {};
+        hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
 };
 
 namespace
@@ -262,45 +268,104 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int Bz = (MODE == MODE_STEP) ? 1 : c->cfg.batch;
         (void)grid;
-        // in step mode the kernels index the filter through blockIdx: give them a view shifted to filter sa.traj
-        DevView dv = c->dv;
-        LargeView<T> v = lv;
-        int *skip = c->skipped;
-        if (MODE == MODE_STEP)
+        // the kernels index the filter through blockIdx: a group of filters starting at b0 gets views shifted to b0
+        struct Group
         {
-                const size_t b = (size_t)sa.traj, np = (size_t)NP;
-                dv.X += b * np;
-                dv.Z += b * np;
-                dv.A += 2 * b;
-                dv.n += b;
-                dv.flags += b;
-                dv.status += b;
-                dv.sens_n += b;
-                dv.wait_n += b;
-                v.P += b * np * np;
-                v.G += b * np * np;
-                v.S += b * np * np;
-                v.Hc += b * (np / 2) * 4;
-                v.Linv += b * LB * LB;
-                v.Y += b * np;
-                skip += b;
-                sa.traj = 0;
-        }
-        for (int s = 0; s < nsteps; ++s)
-        {
-                hipLaunchKernelGGL(fk, dim3(Bz), dim3(SMALL_WG), lds, st, dv, v, t0 + s, s, nsteps, poses, dims, sa, skip);
-                hipLaunchKernelGGL(large_build_GS<T>, dim3(2 + NP / 2, Bz), dim3(256), 0, st, dv, v, skip);
+                DevView dv;
+                LargeView<T> v;
+                int *skip;
+                double *poses;
+                int32_t *dims;
+                int nb;
+                hipStream_t st;
+        };
+        auto make_group = [&](int b0, int nb, hipStream_t gst) {
+                Group g = {c->dv, lv, c->skipped, poses, dims, nb, gst};
+                const size_t b = (size_t)b0, np = (size_t)NP, T_ = (size_t)c->dv.T;
+                g.dv.X += b * np;
+                g.dv.Z += b * np;
+                g.dv.A += 2 * b;
+                g.dv.n += b;
+                g.dv.flags += b;
+                g.dv.status += b;
+                g.dv.sens += b * (size_t)c->dv.max_obs * 2;
+                g.dv.sens_n += b;
+                g.dv.wait_rb += b * (size_t)c->dv.max_wait * 2;
+                g.dv.wait_cnt += b * (size_t)c->dv.max_wait;
+                g.dv.wait_n += b;
+                if (MODE == MODE_REPLAY && b0 > 0)
+                {
+                        g.dv.tr_pose += 2 * b * T_;
+                        g.dv.tr_yaw += b * T_;
+                        g.dv.tr_twist += 2 * b * T_;
+                        g.dv.tr_dt += b * T_;
+                        g.dv.tr_new += b * T_;
+                        g.dv.tr_nobs += b * T_;
+                        g.dv.tr_obs += b * T_ * (size_t)c->dv.max_obs * 2;
+                        if (g.poses)
+                                g.poses += b * (size_t)nsteps * 3;
+                        if (g.dims)
+                                g.dims += b * (size_t)nsteps;
+                }
+                g.v.P += b * np * np;
+                g.v.G += b * np * np;
+                g.v.S += b * np * np;
+                g.v.Hc += b * (np / 2) * 4;
+                g.v.Linv += b * LB * LB;
+                g.v.Y += b * np;
+                g.skip += b;
+                return g;
+        };
+        auto chain = [&](const Group &g, int s) {
+                const int gb = g.nb;
+                hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
+                hipLaunchKernelGGL(large_build_GS<T>, dim3(2 + NP / 2, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                 for (int k = 0; k < NB; ++k)
                 {
-                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(Bz), dim3(64), 0, st, dv, v, k, skip);
-                        hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, Bz), dim3(256), 0, st, dv, v, k, skip);
+                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                        hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, g.skip);
                 }
+                const int ntile = (NP + 127) / 128;
+                hipLaunchKernelGGL(large_syrk<T>, dim3(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8)), dim3(256), 0, g.st, g.dv, g.v, gb,
+                                   g.skip);
+                hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
+                                   g.dims, g.skip);
+        };
+        constexpr int NG = aslam_ctx::LARGE_GROUPS;
+        if (MODE == MODE_STEP)
+        {
+                Group g = make_group(sa.traj, 1, st);
+                sa.traj = 0;
+                for (int s = 0; s < nsteps; ++s)
+                        chain(g, s);
+        }
+        else if (Bz < 8 * NG)
+        {
+                Group g = make_group(0, Bz, st);
+                for (int s = 0; s < nsteps; ++s)
+                        chain(g, s);
+        }
+        else
+        {
+                Group g[NG];
+                const int per = ((Bz + NG - 1) / NG + 7) & ~7; // multiples of 8: large_syrk deals filters to the 8 XCDs
+                for (int q = 0; q < NG; ++q)
                 {
-                        const int ntile = (NP + 127) / 128;
-                        hipLaunchKernelGGL(large_syrk<T>, dim3(8 * (ntile * (ntile + 1) / 2) * ((Bz + 7) / 8)), dim3(256), 0, st, dv, v, Bz, skip);
+                        const int b0 = min(q * per, Bz);
+                        g[q] = make_group(b0, min(per, Bz - b0), q == 0 ? st : c->aux[q - 1]);
                 }
-                hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, Bz), dim3(256), 0, st, dv, v, s, nsteps, poses, dims,
-                                   skip);
+                HIP_TRY(hipEventRecord(c->ev_fork, st));
+                for (int q = 1; q < NG; ++q)
+                        HIP_TRY(hipStreamWaitEvent(c->aux[q - 1], c->ev_fork, 0));
+                for (int s = 0; s < nsteps; ++s)
+                        for (int q = 0; q < NG; ++q)
+                                if (g[q].nb > 0)
+                                        chain(g[q], s);
+                for (int q = 1; q < NG; ++q)
+                {
+                        HIP_TRY(hipEventRecord(c->ev_join[q - 1], c->aux[q - 1]));
+                        HIP_TRY(hipStreamWaitEvent(st, c->ev_join[q - 1], 0));
+                }
         }
         HIP_TRY(hipGetLastError());
         return ASLAM_OK;
@@ -422,6 +487,14 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         else
         {
                 A_(dev_alloc(c, &c->skipped, B, c->owned));
+                for (hipStream_t &q : c->aux)
+                        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
+                                rc = ASLAM_ERR_HIP;
+                if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)
+                        rc = ASLAM_ERR_HIP;
+                for (hipEvent_t &e : c->ev_join)
+                        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+                                rc = ASLAM_ERR_HIP;
                 if (cfg->dtype == ASLAM_F32)
                 {
                         c->lv32.NP = c->NP;
@@ -483,6 +556,14 @@ int aslam_destroy(aslam_ctx *c)
                 (void)hipFree(p);
         for (void *p : c->trace_owned)
                 (void)hipFree(p);
+        for (hipStream_t q : c->aux)
+                if (q)
+                        (void)hipStreamDestroy(q);
+        if (c->ev_fork)
+                (void)hipEventDestroy(c->ev_fork);
+        for (hipEvent_t e : c->ev_join)
+                if (e)
+                        (void)hipEventDestroy(e);
         delete c;
         return ASLAM_OK;
 }

@@ -82,6 +82,33 @@ def test_replay_parity(L, T, kw, dtype, built):
         assert max(errs) < tol and core.status(b) == 0
 
 
+def test_replay_parity_stream_groups(built):
+    """A batch of 19 is replayed as groups of filters on separate streams (uneven: the last group is short): trajectories
+    of every group, including the first and last of each, must match the oracle, and poses and dimensions must land in
+    the caller's buffers at the right rows"""
+    import torch
+    from awesomeslam_amd.core import Core, F64
+    from oracle.c_oracle import CFilter
+
+    L, T, B = 80, 70, 19
+    tr = tg.make_traces(L, T, B=B, seed=63)
+    core = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=F64)
+    core.set_trace(tr)
+    poses = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    dims = torch.zeros((B, T), dtype=torch.int32, device="cuda")
+    core.replay(0, T, poses.data_ptr(), dims.data_ptr())
+    torch.cuda.synchronize()
+    for b in (0, 7, 8, 15, 16, 18):
+        o = CFilter("ekf", tg.dim_cap(L))
+        po, do = o.replay(tr[b])
+        Xo, Zo, Po = o.state()
+        X, Z, P = core.state(b)
+        assert np.array_equal(dims.cpu().numpy()[b], do) and np.array_equal(Z, Zo)
+        errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), rel_err(P, Po)
+        print(f"large replay groups b={b} N={core.dim(b)}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        assert max(errs) < REL_TOL and core.status(b) == 0
+
+
 def test_config4_512_landmarks(built):
     """BASELINE configs[3]: EKF, 512 landmarks (state dimension 1027): three growth stages, then steady state; fp64 against
     the oracle at 1e-6, fp32 with its measured error; bookkeeping bit-exact in both."""
