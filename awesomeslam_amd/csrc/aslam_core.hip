@@ -948,8 +948,8 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
         size_t lds = 0;
         if (c->large)
         {
-                std::snprintf(buf, sizeof(buf), "large_gemm_nt<%s,1> (+ %d-launch chain per callback)",
-                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 5 + 3 * (c->NP / LB));
+                std::snprintf(buf, sizeof(buf), "large_update_panel<%s> (%d-launch chain per callback, %d stream groups)",
+                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 4 + 2 * (c->NP / LB), aslam_ctx::LARGE_GROUPS);
                 lds = LargeLds::bytes(c->NP);
         }
         else if (c->cfg.filter == ASLAM_EKF)

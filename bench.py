@@ -181,7 +181,8 @@ def main():
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel_ms": kernel_s * 1e3,
                          "note": "achieved = SURVEY 8(d) algorithmic flops/callback x callbacks x trajectories per launch / "
-                                 "mean launch duration (HIP events on the launch stream); peak = fp64 FMA/MFMA rate"},
+                                 "mean launch duration (HIP events on the launch stream); peak = dense "
+                                 + ("fp32" if large else "fp64") + " MFMA rate (MI355X_MICROARCH.md)"},
         }
         sample = args.cpu_sample
         if sample is None:

@@ -1,0 +1,21 @@
+import sys, ctypes, numpy as np, time
+sys.path.insert(0,'.')
+import torch
+import awesomeslam_amd.core as ac
+ac._CORE = ac._CORE.replace('libaslam_core.so','libaslam_core_stamps.so')
+import awesomeslam_amd.trace as tg
+from awesomeslam_amd.core import Core
+NAMES=['small_load','small_frontend','X, Hc, Y','P predict','small_store']
+L,B=512,8
+tr=tg.make_traces(L,80,B=B,seed=1)
+core=Core('ekf',tg.dim_cap(L),batch=B,max_obs=tr.max_obs,max_wait=2048,dtype=ac.F32)
+core.set_trace(tr)
+core.replay(0,60); torch.cuda.synchronize()
+lib=ac.core_lib()
+a=(ctypes.c_ulonglong*12)(); lib.aslam_debug_stamps(core._h,a); base=np.array(list(a),dtype=np.float64)
+core.replay(60,20); torch.cuda.synchronize()
+lib.aslam_debug_stamps(core._h,a); cyc=(np.array(list(a),dtype=np.float64)-base)/20
+print('large frontend cycles/callback (workgroup 0): total %.0f'%cyc.sum())
+for nm,c in zip(NAMES,cyc): print(f'   {nm:16s} {c:9.0f}')
+for nm,c in zip(['intake+copy','toPoint+narrow','scan','combine+Z','wait walk','A'],cyc[5:11]): print(f'      fe: {nm:16s} {c:9.0f}')
+
