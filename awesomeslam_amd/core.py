@@ -167,7 +167,10 @@ class Core:
 
     def close(self):
         if getattr(self, "_h", None):
-            core_lib().aslam_destroy(self._h)
+            try:
+                core_lib().aslam_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     __del__ = close

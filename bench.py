@@ -48,35 +48,69 @@ def algorithmic_flops(kind, n):
 def cpu_baseline(kind, L, seed, prologue, sample):
     """The C++ oracle (Eigen-free restatement of the reference node, -O2, one core) on a bounded sample of the
     same workload: trajectory 0, `sample` steady-state callbacks after the warm-up prologue."""
-    from oracle.c_oracle import CFilter
+    from oracle.cpu_bench import run
 
+    r = run(kind, L, seed, 0, prologue, sample)
+    el = r["t1"] - r["t0"]
     if L >= 256:
-        # a full-size callback of the as-coded algebra takes seconds at n = 1027: skip the 64-callback warm-up and time
-        # `sample` slam() calls on a synthetic state of the same dimension (same flops: the dense products do not
-        # depend on the values)
-        n = tg.full_dim(L)
-        rng = np.random.default_rng(seed)
-        X = np.concatenate([[0.3, -0.2, 0.4], (np.array([20.0, 0.0]) + 6 * rng.normal(size=(L, 2))).ravel()])
-        A = rng.normal(size=(n, n)) * 0.02
-        P = A @ A.T / n * 20 + np.eye(n) * 0.01
-        o = CFilter(kind, tg.dim_cap(L))
-        o.set_state(n, X, X.copy(), P, 0.07, -0.03)
-        t0 = time.perf_counter()
-        for _ in range(sample):
-            o.slam(0.2, 0.1, 1.0)
-        el = time.perf_counter() - t0
-        return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port",
-                "sample": f"{sample} slam() calls on a synthetic state of the same dimension N={n} (no warm-up: a callback takes "
-                          f"seconds); oracle/aslam_oracle.cpp (as-coded 18 n^3 dense algebra, fp64), g++ -O2, 1 thread, {el:.1f} s"}
-    tr = tg.make_traces(L, prologue + sample, B=1, seed=seed)[0]
-    o = CFilter(kind, tg.dim_cap(L))
-    o.replay(tr.slice(0, prologue))
-    t0 = time.perf_counter()
-    o.replay(tr.slice(prologue, prologue + sample))
-    el = time.perf_counter() - t0
-    return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port",
-            "sample": f"trajectory 0 of the same seed, {sample} steady-state callbacks after a {prologue}-callback "
-                      f"warm-up, N={o.N}; oracle/aslam_oracle.cpp (as-coded 18 n^3 algebra), g++ -O2, 1 thread, {el:.1f} s"}
+        what = (f"{sample} slam() calls on a synthetic state of the same dimension N={r['N']} (no warm-up: a callback takes "
+                f"seconds); oracle/aslam_oracle.cpp (as-coded 18 n^3 dense algebra, fp64), g++ -O2, 1 thread, {el:.1f} s")
+    else:
+        what = (f"trajectory 0 of the same seed, {sample} steady-state callbacks after a {prologue}-callback "
+                f"warm-up, N={r['N']}; oracle/aslam_oracle.cpp (as-coded 18 n^3 algebra), g++ -O2, 1 thread, {el:.1f} s")
+    return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port", "sample": what}
+
+
+def cpu_baseline_all_cores(kind, L, seed, prologue, sample):
+    """the reference node is single-threaded, so "all cores" = one trajectory per host core, one oracle
+    process each (oracle/cpu_bench.py), same bounded sample per process; value = sum of the per-process rates."""
+    import subprocess
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
+    cmd = [sys.executable, "-m", "oracle.cpu_bench", "--kind", kind, "--landmarks", str(L), "--seed", str(seed),
+           "--prologue", str(prologue), "--sample", str(sample)]
+    procs = [subprocess.Popen(cmd + ["--traj", str(b)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for b in range(cores)]
+    res = []
+    for p_ in procs:
+        out, _ = p_.communicate(timeout=600)
+        if p_.returncode == 0 and out.strip():
+            res.append(json.loads(out.strip().splitlines()[-1]))
+    if not res:
+        return None
+    rate = sum(r["steps"] / (r["t1"] - r["t0"]) for r in res)
+    span = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+    overlap = min(r["t1"] for r in res) - max(r["t0"] for r in res)
+    return {"value": rate, "unit": "filter-steps/s", "cores": len(res), "kind": "port",
+            "sample": f"{len(res)} oracle processes side by side, one trajectory each (trajectories 0..{len(res) - 1} of the same "
+                      f"seed), {sample} callbacks per process; value = sum of per-process rates; timed sections span {span:.1f} s "
+                      f"and overlap for {max(overlap, 0.0):.1f} s"}
+
+
+def single_trajectory_latency(kind, L, seed, prologue, C1, large, local, dev):
+    """batch 1 is reported with every number.  One filter alone on the GPU, `C1` steady-state callbacks in one
+    launch (replay seam), HIP events on the launch stream; the second of two launches is reported."""
+    from awesomeslam_amd.core import F32, F64
+    tr = tg.make_traces(L, prologue + 2 * C1, B=1, seed=seed)
+    core = Core(kind, tg.dim_cap(L), batch=1, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
+                dtype=F32 if large else F64)
+    core.set_trace(tr)
+    stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.zeros((1, max(C1, prologue), 3), dtype=torch.float64, device=dev)
+    core.replay(0, prologue, scratch.data_ptr(), None, stream)
+    ms = []
+    for w in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        core.replay(prologue + w * C1, C1, scratch.data_ptr(), None, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ok = core.dim(0) == tg.full_dim(L) and core.status(0) == 0
+    core.close()
+    return {"trajectories": 1, "callbacks_per_launch": C1, "us_per_callback": ms[1] * 1e3 / C1,
+            "filter_steps_per_s": C1 / (ms[1] * 1e-3), "steady_state": bool(ok)}
 
 
 def main():
@@ -184,11 +218,16 @@ def main():
                                  "mean launch duration (HIP events on the launch stream); peak = dense "
                                  + ("fp32" if large else "fp64") + " MFMA rate (MI355X_MICROARCH.md)"},
         }
+        if world == 1:
+            out["single_trajectory"] = single_trajectory_latency(kind, L, args.seed, prologue, min(C, 200), large, local, dev)
         sample = args.cpu_sample
         if sample is None:
             sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000, "ekf512": 3}[args.workload]
         if world == 1 and sample > 0:
             out["cpu_baseline"] = cpu_baseline(kind, L, args.seed, prologue, sample)
+            allc = cpu_baseline_all_cores(kind, L, args.seed, prologue, sample)
+            if allc:
+                out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out))
     adist.finalize()
 

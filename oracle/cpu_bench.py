@@ -1,0 +1,55 @@
+"""TEST / BENCH INFRASTRUCTURE ONLY -- times the CPU oracle (oracle/aslam_oracle.cpp through oracle/c_oracle.py) on one
+trajectory of a bench workload and prints one JSON line.  bench.py's `cpu_baseline` legs start one of these per host core
+(separate processes: the reference node is single-threaded, "all cores" means one trajectory per core).
+Never imported by the product path.
+
+    python -m oracle.cpu_bench --kind ekf --landmarks 64 --seed 1 --traj 3 --prologue 64 --sample 1200
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from awesomeslam_amd import trace as tg  # noqa: E402  (NumPy only)
+from oracle.c_oracle import CFilter  # noqa: E402
+
+
+def run(kind, L, seed, traj, prologue, sample):
+    if L >= 256:
+        # a full-size callback of the as-coded algebra takes seconds at n = 1027: time `sample` slam() calls on a synthetic
+        # state of the same dimension (same flops: the dense products do not depend on the values)
+        n = tg.full_dim(L)
+        rng = np.random.default_rng(seed + 1000 * traj)
+        X = np.concatenate([[0.3, -0.2, 0.4], (np.array([20.0, 0.0]) + 6 * rng.normal(size=(L, 2))).ravel()])
+        A = rng.normal(size=(n, n)) * 0.02
+        P = A @ A.T / n * 20 + np.eye(n) * 0.01
+        o = CFilter(kind, tg.dim_cap(L))
+        o.set_state(n, X, X.copy(), P, 0.07, -0.03)
+        t0 = time.time()
+        for _ in range(sample):
+            o.slam(0.2, 0.1, 1.0)
+        t1 = time.time()
+        return {"steps": sample, "t0": t0, "t1": t1, "N": n}
+    tr = tg.make_traces(L, prologue + sample, B=1, seed=seed, first_traj=traj)[0]
+    o = CFilter(kind, tg.dim_cap(L))
+    o.replay(tr.slice(0, prologue))
+    t0 = time.time()
+    o.replay(tr.slice(prologue, prologue + sample))
+    t1 = time.time()
+    return {"steps": sample, "t0": t0, "t1": t1, "N": int(o.N)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="ekf")
+    ap.add_argument("--landmarks", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--traj", type=int, default=0)
+    ap.add_argument("--prologue", type=int, default=64)
+    ap.add_argument("--sample", type=int, default=1200)
+    a = ap.parse_args()
+    print(json.dumps(run(a.kind, a.landmarks, a.seed, a.traj, a.prologue, a.sample)))
