@@ -31,6 +31,10 @@ NODE_SYMBOLS = (
     "aslam_node_odom_now", "aslam_node_dim", "aslam_node_get", "aslam_node_wait", "aslam_node_core",
     "aslam_host_narrow_odom",
 )
+TRACE_FILE_SYMBOLS = (
+    "aslam_trace_file_open", "aslam_trace_file_close", "aslam_trace_file_error", "aslam_trace_file_dims",
+    "aslam_trace_file_view", "aslam_trace_file_raw", "aslam_trace_file_write",
+)
 
 
 class AslamError(RuntimeError):
@@ -123,6 +127,17 @@ def node_lib():
         L.aslam_node_core.restype = vp
         L.aslam_node_core.argtypes = [vp]
         L.aslam_host_narrow_odom.argtypes = [ctypes.c_int64, pd, pd, pf, pd]
+        # include/aslam_trace_file.h
+        L.aslam_trace_file_error.restype = ctypes.c_char_p
+        L.aslam_trace_file_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+        L.aslam_trace_file_close.argtypes = [vp]
+        L.aslam_trace_file_close.restype = None
+        L.aslam_trace_file_dims.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                            ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.aslam_trace_file_view.argtypes = [vp, ctypes.POINTER(TraceView)]
+        L.aslam_trace_file_raw.argtypes = [vp] + [ctypes.POINTER(vp)] * 5
+        L.aslam_trace_file_write.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                             vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp]
         _node = L
     return _node
 
@@ -134,6 +149,67 @@ def _ptr(a, ct):
 def _chk(rc):
     if rc != 0:
         raise AslamError(f"aslam_core error {rc}: {core_lib().aslam_last_error().decode()}")
+
+
+class TraceFile:
+    """A trace file opened by the C++ host library (include/aslam_trace_file.h)."""
+
+    def __init__(self, path):
+        h = ctypes.c_void_p()
+        if node_lib().aslam_trace_file_open(os.fsencode(path), ctypes.byref(h)) != 0:
+            raise AslamError(node_lib().aslam_trace_file_error().decode())
+        self._h = h
+        B, T, mo, L = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        node_lib().aslam_trace_file_dims(h, ctypes.byref(B), ctypes.byref(T), ctypes.byref(mo), ctypes.byref(L))
+        self.B, self.T, self.max_obs, self.L = B.value, T.value, mo.value, L.value
+
+    def view(self):
+        """The narrowed aslam_trace view (host pointers owned by this object)."""
+        v = TraceView()
+        if node_lib().aslam_trace_file_view(self._h, ctypes.byref(v)) != 0:
+            raise AslamError(node_lib().aslam_trace_file_error().decode())
+        return v
+
+    def arrays(self):
+        """NumPy copies of the narrowed view: pose, yaw, twist, dt, obs_new, n_obs, obs."""
+        v = self.view()
+        B, T, mo = self.B, self.T, self.max_obs
+
+        def arr(ptr, ct, shape):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.zeros(shape, ct)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), (n,)).reshape(shape).copy()
+
+        return (arr(v.pose, ctypes.c_double, (B, T, 2)), arr(v.yaw, ctypes.c_float, (B, T)),
+                arr(v.twist, ctypes.c_double, (B, T, 2)), arr(v.dt, ctypes.c_float, (B, T)),
+                arr(v.obs_new, ctypes.c_uint8, (B, T)), arr(v.n_obs, ctypes.c_int32, (B, T)),
+                arr(v.obs, ctypes.c_float, (B, T, mo, 2)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                node_lib().aslam_trace_file_close(self._h)
+            except TypeError:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def write(path, tr, with_truth=True):
+        """Write a trace.Trace through the C++ writer."""
+        p = lambda a, dt: np.ascontiguousarray(a, dt)  # noqa: E731
+        odom, dt, new, nobs, obs = p(tr.odom, np.float64), p(tr.dt, np.float32), p(tr.obs_new, np.uint8), \
+            p(tr.n_obs, np.int32), p(tr.obs, np.float32)
+        has = bool(with_truth and tr.truth is not None and tr.L > 0)
+        lm = p(tr.landmarks, np.float64) if has else None
+        truth = p(tr.truth, np.float64) if has else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        rc = node_lib().aslam_trace_file_write(os.fsencode(path), tr.B, tr.T, tr.max_obs, int(tr.warmup), vp(odom), vp(dt),
+                                               vp(new), vp(nobs), vp(obs), tr.L if has else 0, vp(lm), vp(truth))
+        if rc != 0:
+            raise AslamError(node_lib().aslam_trace_file_error().decode())
 
 
 def narrow_odom(odom):
@@ -215,6 +291,14 @@ class Core:
         tv = TraceView(trace.T, trace.max_obs, 0, *(arrs[k].ctypes.data for k in ("pose", "yaw", "twist", "dt", "obs_new", "n_obs", "obs")))
         _chk(core_lib().aslam_set_trace(self._h, ctypes.byref(tv)))
         self.T = trace.T
+
+    def set_trace_file(self, tf):
+        """Bind a TraceFile: the C++ host library narrows the messages, aslam_set_trace copies the view to HBM."""
+        if tf.B != self.batch or tf.max_obs != self.max_obs:
+            raise ValueError(f"trace file is B={tf.B}, max_obs={tf.max_obs}; context is B={self.batch}, max_obs={self.max_obs}")
+        v = tf.view()
+        _chk(core_lib().aslam_set_trace(self._h, ctypes.byref(v)))
+        self.T = tf.T
 
     def set_trace_device(self, T, pose, yaw, twist, dt, obs_new, n_obs, obs):
         """Bind device-resident arrays (raw device pointers as ints, e.g. torch.Tensor.data_ptr())."""

@@ -37,6 +37,7 @@ SENSOR_RANGE = float("inf")  # see module docstring; the reference world keeps e
 STOP_STEPS = 14  # > MIN_LANDMARK_OCC (config.h:44) callbacks at rest promote everything in view
 RING_OFFSETS = (-2.25, -0.75, 0.75, 2.25)
 TRACE_MAGIC = "aslam-trace-v1"
+FILE_MAGIC = b"ASLTRC01"  # include/aslam_trace_file.h
 NOISE_SLOTS = 48  # observation-noise draws per callback are max(NOISE_SLOTS, L): never a function of max_obs or B
 OBS_CHUNK = 4096  # callbacks per vectorised chunk when building sensor messages
 
@@ -73,12 +74,63 @@ class Trace:
 
     def __getitem__(self, b):
         return Trajectory(self.odom[b], self.dt[b], self.obs_new[b], self.n_obs[b], self.obs[b],
-                          self.landmarks[b], self.truth[b], self.warmup)
+                          self.landmarks[b], None if self.truth is None else self.truth[b], self.warmup)
 
     def save(self, path):
         np.savez_compressed(path, magic=TRACE_MAGIC, odom=self.odom, dt=self.dt, obs_new=self.obs_new,
                             n_obs=self.n_obs, obs=self.obs, landmarks=self.landmarks, truth=self.truth,
                             warmup=self.warmup)
+
+    # ---- the binary format of include/aslam_trace_file.h (what the C++ host library reads and writes)
+    def to_file(self, path, with_truth=True):
+        """Write an ASLTRC01 file: 64-byte header, then odom / dt / obs_new / n_obs / obs (+ ground truth), each array
+        starting at a multiple of 64 bytes."""
+        B, T = self.B, self.T
+        has_truth = bool(with_truth and self.landmarks is not None and self.truth is not None and self.L > 0)
+        hdr = np.zeros(64, np.uint8)
+        hdr[0:8] = np.frombuffer(FILE_MAGIC, np.uint8)
+        hdr[8:24] = np.array([B, T], "<i8").view(np.uint8)
+        hdr[24:36] = np.array([self.max_obs, self.L if has_truth else 0, self.warmup], "<i4").view(np.uint8)
+        arrays = [np.ascontiguousarray(self.odom, "<f8"), np.ascontiguousarray(self.dt, "<f4"),
+                  np.ascontiguousarray(self.obs_new, np.uint8), np.ascontiguousarray(self.n_obs, "<i4"),
+                  np.ascontiguousarray(self.obs, "<f4")]
+        if has_truth:
+            arrays += [np.ascontiguousarray(self.landmarks, "<f8"), np.ascontiguousarray(self.truth, "<f8")]
+        with open(path, "wb") as f:
+            f.write(hdr.tobytes())
+            pos = 64
+            for a in arrays:
+                pad = (-pos) % 64
+                f.write(b"\0" * pad)
+                f.write(a.tobytes())
+                pos += pad + a.nbytes
+
+    @staticmethod
+    def from_file(path):
+        raw = np.fromfile(path, np.uint8)
+        if raw.size < 64 or raw[0:8].tobytes() != FILE_MAGIC:
+            raise ValueError(f"{path}: not an ASLTRC01 trace file")
+        B, T = (int(v) for v in raw[8:24].view("<i8"))
+        max_obs, L, warmup = (int(v) for v in raw[24:36].view("<i4"))
+        pos = [64]
+
+        def take(dtype, shape):
+            pos[0] += (-pos[0]) % 64
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            if pos[0] + n > raw.size:
+                raise ValueError(f"{path}: truncated")
+            a = raw[pos[0]:pos[0] + n].view(dtype).reshape(shape).copy()
+            pos[0] += n
+            return a
+
+        odom = take("<f8", (B, T, 8))
+        dt = take("<f4", (B, T))
+        obs_new = take(np.uint8, (B, T))
+        n_obs = take("<i4", (B, T))
+        obs = take("<f4", (B, T, max_obs, 2))
+        landmarks = take("<f8", (B, L, 2)) if L > 0 else np.zeros((B, 0, 2))
+        truth = take("<f8", (B, T, 3)) if L > 0 else None
+        return Trace(odom, dt, obs_new, n_obs, obs, landmarks, truth, warmup)
 
     @staticmethod
     def load(path):

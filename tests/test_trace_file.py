@@ -1,0 +1,100 @@
+"""the on-disk trace format (include/aslam_trace_file.h) and the rostopic-dump converter.
+CPU only; the GPU leg (replaying a file) is in tests/test_gpu_ekf.py."""
+import os
+
+import numpy as np
+import pytest
+
+import awesomeslam_amd.trace as tg
+from awesomeslam_amd import core, rosdump
+
+
+def same_trace(a, b, truth=True):
+    for f in ("odom", "dt", "obs_new", "n_obs", "obs"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), f
+    if truth:
+        assert np.array_equal(a.landmarks, b.landmarks) and np.array_equal(a.truth, b.truth) and a.warmup == b.warmup
+
+
+def test_python_and_cxx_agree_on_the_format(built, tmp_path):
+    tr = tg.make_traces(8, 120, B=3, seed=5, sensor_every=2, dt_mode="random")
+    p1, p2 = str(tmp_path / "py.asltrc"), str(tmp_path / "cxx.asltrc")
+    tr.to_file(p1)
+    core.TraceFile.write(p2, tr)
+    assert open(p1, "rb").read() == open(p2, "rb").read()          # byte for byte
+    same_trace(tg.Trace.from_file(p2), tr)
+    f = core.TraceFile(p1)
+    assert (f.B, f.T, f.max_obs, f.L) == (tr.B, tr.T, tr.max_obs, tr.L)
+    pose, yaw, twist, dt, new, nobs, obs = f.arrays()
+    rp, ry, rt = core.narrow_odom(tr.odom)                           # what Core.set_trace binds
+    assert np.array_equal(pose, rp) and np.array_equal(yaw, ry) and np.array_equal(twist, rt)
+    assert np.array_equal(dt, tr.dt) and np.array_equal(new, tr.obs_new) and np.array_equal(nobs, tr.n_obs)
+    assert np.array_equal(obs, tr.obs)
+    f.close()
+
+
+def test_without_ground_truth_and_errors(built, tmp_path):
+    tr = tg.make_traces(5, 40, B=1, seed=6)
+    p = str(tmp_path / "t.asltrc")
+    core.TraceFile.write(p, tr, with_truth=False)
+    back = tg.Trace.from_file(p)
+    same_trace(back, tr, truth=False)
+    assert back.L == 0 and back.truth is None
+    with pytest.raises(core.AslamError):
+        core.TraceFile(str(tmp_path / "missing.asltrc"))
+    bad = str(tmp_path / "bad.asltrc")
+    open(bad, "wb").write(b"not a trace file at all" * 8)
+    with pytest.raises(core.AslamError):
+        core.TraceFile(bad)
+    with pytest.raises(ValueError):
+        tg.Trace.from_file(bad)
+    cut = str(tmp_path / "cut.asltrc")
+    open(cut, "wb").write(open(p, "rb").read()[:-100])
+    with pytest.raises(core.AslamError):
+        core.TraceFile(cut)
+    with pytest.raises(ValueError):
+        tg.Trace.from_file(cut)
+
+
+@pytest.mark.parametrize("extra", [0, 2])
+def test_rostopic_dump_round_trip(extra):
+    """Trajectory -> the two `rostopic echo -p` texts -> trace: every array bit for bit, older messages in the size-1
+    queues dropped, dt = the node's min(now - last_time, 1.0)."""
+    tr = tg.make_traces(8, 90, B=1, seed=7, sensor_every=3)
+    ocsv, lcsv = rosdump.dump_csv(tr[0], extra_dropped=extra, seed=extra)
+    back = rosdump.to_trace(ocsv, lcsv, t_start_ns=rosdump.DUMP_T0_NS)
+    assert back.T == tr.T and back.max_obs == tr.max_obs
+    assert np.array_equal(back.odom, tr.odom[:1]) and np.array_equal(back.obs_new, tr.obs_new[:1])
+    new = tr.obs_new[:1].astype(bool)           # the generator repeats the stored message on callbacks without a new one;
+    assert np.array_equal(back.n_obs, tr.n_obs[:1] * new)   # only delivered messages exist in a recording
+    assert np.array_equal(back.obs[new], tr.obs[:1][new]) and not back.obs[~new].any()
+    assert back.dt.dtype == np.float32 and np.array_equal(back.dt, np.ones_like(back.dt))   # 1 Hz spin: dt clamps to 1.0
+
+
+def test_rostopic_dump_feeds_the_oracle_identically():
+    from oracle.c_oracle import CFilter
+
+    tr = tg.make_traces(5, 80, B=1, seed=8)
+    back = rosdump.to_trace(*rosdump.dump_csv(tr[0]), t_start_ns=rosdump.DUMP_T0_NS)
+    a, b = CFilter("ekf", tg.dim_cap(5)), CFilter("ekf", tg.dim_cap(5))
+    pa, da = a.replay(tr[0])
+    pb, db = b.replay(back[0])
+    assert np.array_equal(pa, pb) and np.array_equal(da, db)
+
+
+def test_spin_semantics():
+    """Two spins without odometry, a Landmarks message waiting for the next odometry callback, the init_z gate."""
+    hdr = ",".join(["%time"] + list(rosdump.ODOM_FIELDS))
+    row = lambda t, v: ",".join([str(int(t * 1e9))] + [repr(float(v))] * 8)  # noqa: E731
+    odom = "\n".join([hdr, row(100.2, 1), row(100.6, 2), row(103.4, 3), row(104.5, 4)]) + "\n"
+    lms = "%time,field.x0,field.y0\n" + f"{int(102.5e9)},1.5,2.5,0.25,0.5\n"
+    tr = rosdump.to_trace(odom, lms, t_start_ns=int(100e9))
+    # spin 101: odometry 2 (1 dropped), no landmarks yet -> early-return callback; spins 102, 103: nothing / landmarks only;
+    # spin 104: odometry 3 with the waiting Landmarks message; spin 105: odometry 4
+    assert tr.T == 3 and list(tr.odom[0, :, 0]) == [2.0, 3.0, 4.0]
+    assert list(tr.obs_new[0]) == [0, 1, 0] and list(tr.n_obs[0]) == [0, 2, 0]
+    assert np.array_equal(tr.obs[0, 1], np.array([[1.5, 0.25], [2.5, 0.5]], np.float32))
+    assert list(tr.dt[0]) == [1.0, 1.0, 1.0]
+    fast = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(100e9))
+    assert fast.dt[0, -1] == np.float32(0.25) or fast.dt[0, -1] == np.float32(1.0)
