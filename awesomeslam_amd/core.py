@@ -151,6 +151,38 @@ def _chk(rc):
         raise AslamError(f"aslam_core error {rc}: {core_lib().aslam_last_error().decode()}")
 
 
+SCAN_SYMBOLS = ("aslam_scan_landmarks",)
+SCAN_BEAMS = 360
+SCAN_REF_ABORT, SCAN_OVERFLOW = 1, 2
+
+
+def scan_landmarks(ranges, max_out=64, device=0):
+    """include/aslam_scan.h on host arrays: ranges [count, 360] f32 -> (n [count] i32, range [count, max_out] f32,
+    bearing [count, max_out] f32, status [count] u32).  Runs on the GPU; there is no CPU fallback."""
+    r = np.ascontiguousarray(ranges, np.float32)
+    if r.ndim != 2 or r.shape[1] != SCAN_BEAMS:
+        raise ValueError("ranges must be [count, 360]")
+    cnt = r.shape[0]
+    rg = np.zeros((cnt, max_out), np.float32)
+    bg = np.zeros((cnt, max_out), np.float32)
+    n = np.zeros(cnt, np.int32)
+    st = np.zeros(cnt, np.uint32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    lib = core_lib()
+    lib.aslam_scan_landmarks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    _chk(lib.aslam_scan_landmarks(vp(r), cnt, 0, int(max_out), vp(rg), vp(bg), vp(n), vp(st), int(device), None))
+    return n, rg, bg, st
+
+
+def scan_landmarks_device(ranges_ptr, count, max_out, range_ptr, bearing_ptr, n_ptr, status_ptr, device=0, stream=None):
+    """include/aslam_scan.h on device pointers (ints), asynchronous on `stream`."""
+    lib = core_lib()
+    lib.aslam_scan_landmarks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    _chk(lib.aslam_scan_landmarks(ranges_ptr, int(count), 1, int(max_out), range_ptr, bearing_ptr, n_ptr, status_ptr, int(device), stream))
+
+
 class TraceFile:
     """A trace file opened by the C++ host library (include/aslam_trace_file.h)."""
 

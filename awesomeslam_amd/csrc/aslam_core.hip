@@ -3,6 +3,7 @@
 // Build (see Makefile): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 // No CPU fallback exists: without a HIP device every compute entry point returns ASLAM_ERR_HIP.
 #include "../../include/aslam_core.h"
+#include "../../include/aslam_scan.h"
 
 #include <hip/hip_runtime.h>
 
@@ -14,6 +15,7 @@
 
 #include "ekf_small.h"
 #include "ekf_large.h"
+#include "scan_front.h"
 #if ASLAM_HAVE_UKF
 #include "ukf_small.h"
 #endif
@@ -939,6 +941,100 @@ int aslam_debug_wave_busy(aslam_ctx *c, unsigned long long *out24)
         return ASLAM_OK;
 }
 #endif
+
+/* ---- include/aslam_scan.h ------------------------------------------------------------------------------------------ */
+namespace
+{
+constexpr int MAX_SCAN_DEVICES = 16;
+static float *g_scan_tables[MAX_SCAN_DEVICES] = {}; // [2][360]: cos_map, sin_map of LandMarks::initialize (sensor_landmark.cpp:49-56)
+
+static int scan_tables(int device, float **out)
+{
+        if (device < 0 || device >= MAX_SCAN_DEVICES)
+                return fail(ASLAM_ERR_ARG, "device index out of range");
+        if (!g_scan_tables[device])
+        {
+                // the reference fills them with the host libm's binary32 sin / cos of DEG2RAD * float(theta): so does this
+                const float DEG2RAD = 0.01745329251f; // config.h:41
+                float tab[2 * SCAN_BEAMS];
+                for (int t = 0; t < SCAN_BEAMS; ++t)
+                {
+                        tab[t] = std::cos(DEG2RAD * static_cast<float>(t));
+                        tab[SCAN_BEAMS + t] = std::sin(DEG2RAD * static_cast<float>(t));
+                }
+                float *p = nullptr;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), sizeof(tab)));
+                HIP_TRY(hipMemcpy(p, tab, sizeof(tab), hipMemcpyHostToDevice));
+                g_scan_tables[device] = p;
+        }
+        *out = g_scan_tables[device];
+        return ASLAM_OK;
+}
+} // namespace
+
+int aslam_scan_landmarks(const float *ranges, int64_t count, int is_device, int max_out, float *range_out, float *bearing_out,
+                         int32_t *n_out, uint32_t *status_out, int device, void *stream)
+{
+        if (!ranges || !range_out || !bearing_out || !n_out || !status_out || count < 0 || max_out <= 0)
+                return fail(ASLAM_ERR_ARG, "aslam_scan_landmarks: bad argument");
+        if (count == 0)
+                return ASLAM_OK;
+        HIP_TRY(hipSetDevice(device));
+        float *tab = nullptr;
+        int rc = scan_tables(device, &tab);
+        if (rc != ASLAM_OK)
+                return rc;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const size_t n = (size_t)count;
+        if (is_device)
+        {
+                hipLaunchKernelGGL(scan_landmarks_kernel, dim3((unsigned)count), dim3(64), 0, st, ranges, tab, tab + SCAN_BEAMS, count, max_out,
+                                   range_out, bearing_out, n_out, status_out);
+                HIP_TRY(hipGetLastError());
+                return ASLAM_OK;
+        }
+        float *d_in = nullptr, *d_r = nullptr, *d_b = nullptr;
+        int32_t *d_n = nullptr;
+        uint32_t *d_s = nullptr;
+        auto cleanup = [&]() {
+                (void)hipFree(d_in), (void)hipFree(d_r), (void)hipFree(d_b), (void)hipFree(d_n), (void)hipFree(d_s);
+        };
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), n * SCAN_BEAMS * sizeof(float));
+        if (e == hipSuccess)
+                e = hipMalloc(reinterpret_cast<void **>(&d_r), n * max_out * sizeof(float));
+        if (e == hipSuccess)
+                e = hipMalloc(reinterpret_cast<void **>(&d_b), n * max_out * sizeof(float));
+        if (e == hipSuccess)
+                e = hipMalloc(reinterpret_cast<void **>(&d_n), n * sizeof(int32_t));
+        if (e == hipSuccess)
+                e = hipMalloc(reinterpret_cast<void **>(&d_s), n * sizeof(uint32_t));
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(d_in, ranges, n * SCAN_BEAMS * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+                e = hipMemsetAsync(d_r, 0, n * max_out * sizeof(float), st);
+        if (e == hipSuccess)
+                e = hipMemsetAsync(d_b, 0, n * max_out * sizeof(float), st);
+        if (e == hipSuccess)
+        {
+                hipLaunchKernelGGL(scan_landmarks_kernel, dim3((unsigned)count), dim3(64), 0, st, d_in, tab, tab + SCAN_BEAMS, count, max_out, d_r,
+                                   d_b, d_n, d_s);
+                e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(range_out, d_r, n * max_out * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(bearing_out, d_b, n * max_out * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(n_out, d_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(status_out, d_s, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+        cleanup();
+        if (e != hipSuccess)
+                return fail(ASLAM_ERR_HIP, std::string("aslam_scan_landmarks: ") + hipGetErrorString(e));
+        return ASLAM_OK;
+}
 
 int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *block, int *lds_bytes)
 {

@@ -36,6 +36,14 @@ def test_node_exports_every_declared_symbol(built):
         assert hasattr(lib, n), n
 
 
+def test_scan_api_is_exported(built):
+    names = declared(os.path.join(ROOT, "include", "aslam_scan.h"))
+    assert sorted(names) == sorted(core.SCAN_SYMBOLS)
+    lib = ctypes.CDLL(os.path.join(ROOT, "awesomeslam_amd", "csrc", "libaslam_core.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+
+
 def test_trace_file_api_is_exported(built):
     names = [n for n in declared(os.path.join(ROOT, "include", "aslam_trace_file.h")) if n.startswith("aslam_trace_file_")]
     assert sorted(names) == sorted(core.TRACE_FILE_SYMBOLS)

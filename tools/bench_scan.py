@@ -1,0 +1,53 @@
+"""Throughput of the scan -> (range, bearing) front end (include/aslam_scan.h): scans resident in HBM,
+HIP events around the launches; the NumPy oracle timed beside it on a bounded sample.  One JSON line.
+
+    python tools/bench_scan.py [--scans 262144] [--reps 10]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from awesomeslam_amd.core import scan_landmarks_device
+from oracle import scan_oracle as so
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scans", type=int, default=262144)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--max-out", type=int, default=32)
+a = ap.parse_args()
+
+base = so.make_scans(2048, seed=9)
+host = np.tile(base, (a.scans // len(base) + 1, 1))[:a.scans]
+dev = torch.device("cuda", 0)
+r = torch.from_numpy(host).to(dev)
+rg = torch.zeros((a.scans, a.max_out), dtype=torch.float32, device=dev)
+bg = torch.zeros_like(rg)
+n = torch.zeros(a.scans, dtype=torch.int32, device=dev)
+st = torch.zeros(a.scans, dtype=torch.int32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+run = lambda: scan_landmarks_device(r.data_ptr(), a.scans, a.max_out, rg.data_ptr(), bg.data_ptr(), n.data_ptr(), st.data_ptr(), 0, stream)
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+nl = int(n.sum().item())
+# parity spot check of the timed data against the oracle (first 64 scans)
+nn, rr, bb = n.cpu().numpy(), rg.cpu().numpy(), bg.cpu().numpy()
+for i in range(64):
+    ost, orr, ob = so.scan(host[i])
+    assert nn[i] == len(orr) and np.array_equal(rr[i, :nn[i]], orr) and np.array_equal(bb[i, :nn[i]], ob), i
+t = time.perf_counter(); cnt = 0
+while time.perf_counter() - t < 10.0:
+    so.scan(host[cnt % len(host)]); cnt += 1
+cpu = cnt / (time.perf_counter() - t)
+bytes_per_scan = 360 * 4 + 8 + 8 * nl / a.scans
+print(json.dumps({"metric": "laser scans/s -> landmark lists", "value": a.scans / (ms * 1e-3), "unit": "scans/s", "scans_per_launch": a.scans,
+                  "ms_per_launch": ms, "landmarks_per_scan": nl / a.scans, "dtype": "f32 (+ f64 4x4 algebra)",
+                  "roofline": {"bound": "hbm", "achieved": a.scans * bytes_per_scan / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": a.scans * bytes_per_scan / (ms * 1e-3) / 1e9 / 8000.0,
+                               "note": "algorithmic bytes = 1440 B of ranges + the landmark list per scan; the kernel is bound by per-lane sequential cluster work (one lane per cluster), not by HBM"},
+                  "cpu_baseline": {"value": cpu, "unit": "scans/s", "cores": 1, "kind": "port",
+                                   "sample": f"{cnt} scans in 10 s, oracle/scan_oracle.py (NumPy restatement, LAPACK SVD/eigh)"}}))
