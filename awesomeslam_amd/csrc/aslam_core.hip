@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -952,6 +953,8 @@ static int scan_tables(int device, float **out)
 {
         if (device < 0 || device >= MAX_SCAN_DEVICES)
                 return fail(ASLAM_ERR_ARG, "device index out of range");
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
         if (!g_scan_tables[device])
         {
                 // the reference fills them with the host libm's binary32 sin / cos of DEG2RAD * float(theta): so does this
