@@ -38,6 +38,7 @@ PEAK_F32_TFLOPS = 157.3
 # fp64 peak: 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz = 78.6 TFLOP/s, for v_fma_f64 and v_mfma_f64 alike
 # (= half of the 157.3 TFLOP/s FP32 row of MI355X_MICROARCH.md, which lists no fp64 row of its own)
 PEAK_F64_TFLOPS = 78.6
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
 
 
 def algorithmic_flops(kind, n):
@@ -213,6 +214,9 @@ def main():
                        "trace_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
+                         # the other roofline north_star asks for: PMC bytes at the L2's memory side per launch / launch time
+                         "hbm": None if traffic is None else {"achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                                              "frac": traffic / kernel_s / 1e9 / PEAK_HBM_GBPS},
                          "kernel_ms": kernel_s * 1e3,
                          "note": "achieved = SURVEY 8(d) algorithmic flops/callback x callbacks x trajectories per launch / "
                                  "mean launch duration (HIP events on the launch stream); peak = dense "
