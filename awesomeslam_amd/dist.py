@@ -22,7 +22,9 @@ def init(backend=None):
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ASLAM_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks (the ranks then
+            # share devices and CUDA tensors are staged through host memory for the collectives)
+            backend = os.environ.get("ASLAM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -38,10 +40,15 @@ def barrier():
         dist.barrier()
 
 
+def _coll_device(device):
+    """gloo moves CPU tensors; nccl (RCCL) needs them on the rank's GPU"""
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def max_over_ranks(x, device="cpu"):
     if not dist.is_initialized():
         return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -49,7 +56,7 @@ def max_over_ranks(x, device="cpu"):
 def sum_over_ranks(x, device="cpu"):
     if not dist.is_initialized():
         return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -59,9 +66,12 @@ def gather_poses(poses):
     if not dist.is_initialized():
         return poses
     world = dist.get_world_size()
-    out = torch.empty((world * poses.shape[0],) + tuple(poses.shape[1:]), dtype=poses.dtype, device=poses.device)
-    dist.all_gather_into_tensor(out, poses.contiguous())  # concatenation along dim 0, in rank order
-    return out
+    src = poses.contiguous()
+    if dist.get_backend() == "gloo" and src.is_cuda:
+        src = src.cpu()  # rehearsal: staged through host memory
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)  # concatenation along dim 0, in rank order
+    return out.to(poses.device)
 
 
 def finalize():

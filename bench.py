@@ -133,6 +133,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the filter core has no CPU fallback")
+    local = local % torch.cuda.device_count()  # ranks share devices only in the gloo rehearsal (ASLAM_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -167,6 +168,7 @@ def main():
             raise SystemExit(f"trajectory {b}: N={core.dim(b)} (want {n_full}), status={core.status(b)} after the warm-up")
     for w in range(W):
         core.replay(prologue + w * C, C, scratch.data_ptr(), None, stream)
+    adist.gather_poses(scratch[:, :1])  # the collective once, untimed: communicator and buffers exist when the clock starts
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
