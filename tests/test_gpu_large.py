@@ -136,3 +136,23 @@ def test_config4_512_landmarks(built):
         errs = rel_err(poses.cpu().numpy()[0], po), rel_err(X, Xo), rel_err(P, Po)
         print(f"config 4 (n=1027) {'f32' if dtype == F32 else 'f64'}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < tol
+
+
+def test_host_mirror_on_the_large_path(built):
+    """The C++ node mirror (per-callback seam: association and growth on the host, slam() through aslam_ekf_step) with a
+    state that outgrows the single-CU kernels: 80 landmarks, n = 163, fp64 large path, growth in several stages."""
+    from awesomeslam_amd.core import Node
+    from oracle.c_oracle import CFilter
+
+    L, T = 80, 75
+    tr = tg.make_traces(L, T, B=1, seed=64)[0]
+    node = Node("ekf", tg.dim_cap(L))
+    pn, dn = node.replay(tr)
+    o = CFilter("ekf", tg.dim_cap(L))
+    po, do = o.replay(tr)
+    Xo, Zo, Po = o.state()
+    X, Z, a00, a10 = node.state()
+    assert dn[-1] == tg.full_dim(L) and np.array_equal(dn, do) and np.array_equal(Z, Zo) and (a00, a10) == o.A()
+    errs = rel_err(pn, po), rel_err(X, Xo), rel_err(node.P(), Po)
+    print(f"host mirror on the large path N={dn[-1]}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    assert max(errs) < REL_TOL
