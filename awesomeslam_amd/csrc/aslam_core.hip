@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -66,6 +68,7 @@ struct aslam_ctx
         // launches of one group (one-wave diagonal factorisations, the front end, short-K panels) then overlap the GEMMs of
         // the others
         static constexpr int LARGE_GROUPS = 4;
+        int large_groups = LARGE_GROUPS; // ASLAM_LARGE_GROUPS=1..4 overrides (1 = a single stream, for per-kernel profiling)
         hipStream_t aux[LARGE_GROUPS - 1] = {};
         hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
 };
@@ -334,7 +337,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
                                    g.dims, g.skip);
         };
-        constexpr int NG = aslam_ctx::LARGE_GROUPS;
+        const int NG = c->large_groups;
         if (MODE == MODE_STEP)
         {
                 Group g = make_group(sa.traj, 1, st);
@@ -350,7 +353,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         }
         else
         {
-                Group g[NG];
+                Group g[aslam_ctx::LARGE_GROUPS];
                 const int per = ((Bz + NG - 1) / NG + 7) & ~7; // multiples of 8: large_syrk deals filters to the 8 XCDs
                 for (int q = 0; q < NG; ++q)
                 {
@@ -490,6 +493,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         else
         {
                 A_(dev_alloc(c, &c->skipped, B, c->owned));
+                if (const char *e = std::getenv("ASLAM_LARGE_GROUPS"))
+                        c->large_groups = std::max(1, std::min((int)aslam_ctx::LARGE_GROUPS, std::atoi(e)));
                 for (hipStream_t &q : c->aux)
                         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
                                 rc = ASLAM_ERR_HIP;
@@ -1048,7 +1053,7 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
         if (c->large)
         {
                 std::snprintf(buf, sizeof(buf), "large_update_panel<%s> (%d-launch chain per callback, %d stream groups)",
-                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 4 + 2 * (c->NP / LB), aslam_ctx::LARGE_GROUPS);
+                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 4 + 2 * (c->NP / LB), c->large_groups);
                 lds = LargeLds::bytes(c->NP);
         }
         else if (c->cfg.filter == ASLAM_EKF)
