@@ -12,8 +12,12 @@ which is why the interleaving has to be part of the trace.  `dt[t]` is the binar
 would have computed from ros::Time (ekf.cpp:80).
 
 The generator is deterministic in (seed, trajectory index) and ROS-free.  Scenario: L
-landmarks on four jittered rings (pairwise spacing > 2 x MIN_DIST_THRESH) around a closed loop.  Two
-properties of the reference shape it:
+landmarks (pairwise spacing > 2 x MIN_DIST_THRESH) and a robot on a small closed loop.  Default layout
+"field": the landmarks sit on a jittered grid EAST of the loop (nearest column FIELD_X0 = 12 m away), so
+that every bearing stays well inside (-pi, pi): the reference UKF averages wrapped angles with a negative
+central weight (ukf.cpp:296-303) and loses positive definiteness as soon as sigma-point bearings straddle
++-pi; layout "ring" (EKF only) puts them on four rings around the loop.  Two more properties of the
+reference shape the scenario:
   * a landmark that is not re-observed keeps its stale range/bearing in Z and is still used in every
     update (ekf.cpp:175-181,300-310), so -- as in the reference's own Gazebo world, where all 8
     cylinders sit inside the lidar's range -- every mapped landmark must stay visible: the default
