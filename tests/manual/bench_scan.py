@@ -1,10 +1,10 @@
 """Throughput of the scan -> (range, bearing) front end (include/aslam_scan.h): scans resident in HBM,
 HIP events around the launches; the NumPy oracle timed beside it on a bounded sample.  One JSON line.
 
-    python tools/bench_scan.py [--scans 262144] [--reps 10]
+    python tests/manual/bench_scan.py [--scans 262144] [--reps 10]
 """
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from awesomeslam_amd.core import scan_landmarks_device

@@ -5,7 +5,7 @@
   part 2  EKF, 64 landmarks, fp64: 100 000 callbacks for 64 filters (status, finiteness, pose error against the simulated
           truth), and parity of trajectory 0 against the CPU oracle over the first 20 000 callbacks
 
-    python tools/long_run.py [--t512 20000] [--t64 100000] [--oracle 20000]
+    python tests/manual/long_run.py [--t512 20000] [--t64 100000] [--oracle 20000]
 """
 import argparse, sys, time
 import numpy as np
