@@ -5,6 +5,113 @@
 
 namespace aslam
 {
+/// coefficient rows of landmark i acting on (p0, p1, p2, l_a, l_b): FWD = the two rows of H (updateH, ekf.cpp:117-134),
+/// otherwise the two rows of H^-1 (hc[4..7] = inverse of the landmark's 2x2 block)
+template <bool FWD> __device__ __forceinline__ void lm_coef(const double *hc, double (&C)[2][5])
+{
+        if (FWD)
+        {
+                C[0][0] = hc[0], C[0][1] = hc[1], C[0][2] = 0.0, C[0][3] = -hc[0], C[0][4] = -hc[1];
+                C[1][0] = hc[2], C[1][1] = hc[3], C[1][2] = -1.0, C[1][3] = -hc[2], C[1][4] = -hc[3];
+        }
+        else
+        {
+                C[0][0] = 1.0, C[0][1] = 0.0, C[0][2] = -hc[5], C[0][3] = -hc[4], C[0][4] = -hc[5];
+                C[1][0] = 0.0, C[1][1] = 1.0, C[1][2] = -hc[7], C[1][3] = -hc[6], C[1][4] = -hc[7];
+        }
+}
+
+/// P <- T P T^T on the symmetric P held as lower tiles in LDS, T = H (FWD) or H^-1.  T is the identity on the pose and
+/// couples landmark i only to the pose and to itself, so the 2x2 block (i, j) of the result needs the pose block, the pose
+/// columns of landmarks i and j and its own old value: after a side copy of the pose columns (`pose`: [n][3], LDS)
+/// every block is transformed in place by one thread, in one pass.  Ends with a barrier.
+template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt, double *pose, const double *sH, int n, int nl, int tid)
+{
+        for (int idx = tid; idx < 3 * n; idx += SMALL_WG)
+        {
+                const int r = idx / 3, k = idx - 3 * r;
+                pose[idx] = sym_get(Lt, r, k);
+        }
+        __syncthreads();
+        const int npair = nl * (nl + 1) / 2;
+        for (int w = tid; w < npair + nl; w += SMALL_WG)
+        {
+                if (w < nl)
+                {
+                        // landmark-pose block: rows 3+2i, 4+2i; columns 0..2
+                        const int i = w, ra = 3 + 2 * i;
+                        double C[2][5];
+                        lm_coef<FWD>(sH + 8 * i, C);
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+#pragma unroll
+                                for (int k = 0; k < 3; ++k)
+                                {
+                                        double v = C[x][3] * pose[3 * ra + k] + C[x][4] * pose[3 * (ra + 1) + k];
+#pragma unroll
+                                        for (int m = 0; m < 3; ++m)
+                                                v = fma(C[x][m], pose[3 * m + k], v);
+                                        *tile_elem(Lt, ra + x, k) = v;
+                                }
+                        continue;
+                }
+                const int q = w - nl;
+                int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= q)
+                        ++i;
+                while (i * (i + 1) / 2 > q)
+                        --i;
+                const int j = q - i * (i + 1) / 2; // j <= i
+                const int ra = 3 + 2 * i, ca = 3 + 2 * j;
+                double Ci[2][5], Cj[2][5];
+                lm_coef<FWD>(sH + 8 * i, Ci);
+                lm_coef<FWD>(sH + 8 * j, Cj);
+                // M: rows (p0, p1, p2, a_i, b_i) x columns (p0, p1, p2, a_j, b_j) of the old P
+                double M[5][5];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                                M[m][k] = pose[3 * m + k];
+                        M[m][3] = pose[3 * ca + m];
+                        M[m][4] = pose[3 * (ca + 1) + m];
+                        M[3][m] = pose[3 * ra + m];
+                        M[4][m] = pose[3 * (ra + 1) + m];
+                }
+                M[3][3] = *tile_elem(Lt, ra, ca);
+                M[4][3] = *tile_elem(Lt, ra + 1, ca);
+                M[4][4] = *tile_elem(Lt, ra + 1, ca + 1);
+                M[3][4] = (i == j) ? M[4][3] : *tile_elem(Lt, ra, ca + 1);
+                double W[2][5];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k)
+                        {
+                                double v = Ci[x][0] * M[0][k];
+#pragma unroll
+                                for (int m = 1; m < 5; ++m)
+                                        v = fma(Ci[x][m], M[m][k], v);
+                                W[x][k] = v;
+                        }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y)
+                        {
+                                if (i == j && y > x)
+                                        continue; // the diagonal block is symmetric: lower entries only
+                                double v = W[x][0] * Cj[y][0];
+#pragma unroll
+                                for (int k = 1; k < 5; ++k)
+                                        v = fma(W[x][k], Cj[y][k], v);
+                                *tile_elem(Lt, ra + x, ca + y) = v;
+                        }
+        }
+        __syncthreads();
+}
+
 template <int NT, int MODE>
 __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t t0, int nsteps, double *poses_out,
                                                               int32_t *dims_out, StepArgs sa)
@@ -27,13 +134,27 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
 #endif
 
         small_load<MODE>(d, L, b, tid, NP);
+        // P stays in LDS for the whole launch, as the lower 16x16 tiles of the symmetric matrix (the tile storage the solver
+        // factors in place): HBM sees it once on the way in and once on the way out
+        for (int idx = tid; idx < LY::NTILES * 256; idx += SMALL_WG)
+        {
+                const int tl = idx >> 8, e = idx & 255;
+                int ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+                while ((ib + 1) * (ib + 2) / 2 <= tl)
+                        ++ib;
+                while (ib * (ib + 1) / 2 > tl)
+                        --ib;
+                const int jb = tl - ib * (ib + 1) / 2;
+                Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = Pg[(size_t)(16 * ib + (e >> 4)) * NP + 16 * jb + (e & 15)];
+        }
+        __syncthreads();
 
         for (int s = 0; s < nsteps; ++s)
         {
                 const int64_t t = t0 + s;
                 if (MODE == MODE_REPLAY)
                 {
-                        if (small_frontend<true, SMALL_OBS_CAP, SMALL_WAIT_CAP, NP / 2, double>(d, L, Pg, NP, b, t, s, nsteps, poses_out, dims_out, tid))
+                        if (small_frontend<true, SMALL_OBS_CAP, SMALL_WAIT_CAP, NP / 2, double>(d, L, Pg, NP, b, t, s, nsteps, poses_out, dims_out, tid, Lt))
                                 continue;
                 }
                 else
@@ -97,87 +218,41 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 }
                 for (int i = n + tid; i < NP; i += SMALL_WG)
                         sY[i] = 0.0;
-                // P = A P A^T + Q (ekf.cpp:297) with A = I except A(0,0), A(1,0): rows 0,1 then columns 0,1
+                // P = A P A^T + Q (ekf.cpp:297) with A = I except A(0,0), A(1,0): on the symmetric storage that is columns 0, 1 of
+                // the rows below, and the 2x2 corner
+                __syncthreads(); // sY / sH are complete, nobody is still reading P
                 {
                         const double a00 = sm.a00, a10 = sm.a10;
-                        if (tid < n)
+                        for (int r = 2 + tid; r < n; r += SMALL_WG)
                         {
-                                const double r0 = Pg[tid];
-                                Pg[tid] = a00 * r0;
-                                Pg[NP + tid] = a10 * r0 + Pg[NP + tid];
+                                const double p0 = *tile_elem(Lt, r, 0);
+                                *tile_elem(Lt, r, 0) = a00 * p0;
+                                *tile_elem(Lt, r, 1) = a10 * p0 + *tile_elem(Lt, r, 1);
                         }
-                        __syncthreads();
-                        if (tid < n)
+                        if (tid == 0)
                         {
-                                double *row = Pg + (size_t)tid * NP;
-                                const double c0 = row[0];
-                                double v0 = a00 * c0;
-                                double v1 = a10 * c0 + row[1];
-                                if (tid == 0)
-                                        v0 += q_proc;
-                                if (tid == 1)
-                                        v1 += q_proc;
-                                row[0] = v0;
-                                row[1] = v1;
-                                if (tid == 2)
-                                        row[2] += q_proc;
+                                const double p00 = Lt[0], p10 = Lt[TLD], p11 = Lt[TLD + 1];
+                                const double r10 = a10 * p00 + p10; // (A P)(1,0)
+                                Lt[0] = a00 * (a00 * p00) + q_proc;
+                                Lt[TLD] = a00 * r10;
+                                Lt[TLD + 1] = a10 * r10 + (a10 * p10 + p11) + q_proc;
+                                Lt[2 * TLD + 2] += q_proc;
                         }
                         __syncthreads();
                 }
                 ASLAM_STAMP(1);
-                // Pt = H P H^T in place: rows ...
-                for (int idx = tid; idx < nl * n; idx += SMALL_WG)
-                {
-                        const int i = idx / n, c = idx - i * n;
-                        const double *hc = sH + 8 * i;
-                        const double p0 = Pg[c], p1 = Pg[NP + c], p2 = Pg[2 * NP + c];
-                        double *ra = Pg + (size_t)(3 + 2 * i) * NP + c;
-                        const double pa = ra[0], pb = ra[NP];
-                        ra[0] = fma(-hc[1], pb, fma(-hc[0], pa, fma(hc[1], p1, hc[0] * p0)));
-                        ra[NP] = fma(-hc[3], pb, fma(-hc[2], pa, fma(hc[3], p1, hc[2] * p0) - p2));
-                }
-                __syncthreads();
+                // Pt = H P H^T, in place on the tiles (the inverted-diagonal-tile area is free until the solve: side copy of the pose columns)
+                congruence_tiles<true>(Lt, Dinv, sH, n, nl, tid);
                 ASLAM_STAMP(2);
-                // ... then columns
-                for (int idx = tid; idx < n * nl; idx += SMALL_WG)
-                {
-                        const int a = idx / nl, i = idx - a * nl;
-                        const double *hc = sH + 8 * i;
-                        double *row = Pg + (size_t)a * NP;
-                        const double t0_ = row[0], t1_ = row[1], t2_ = row[2];
-                        const double ta = row[3 + 2 * i], tb = row[4 + 2 * i];
-                        row[3 + 2 * i] = fma(-hc[1], tb, fma(-hc[0], ta, fma(hc[1], t1_, hc[0] * t0_)));
-                        row[4 + 2 * i] = fma(-hc[3], tb, fma(-hc[2], ta, fma(hc[3], t1_, hc[2] * t0_) - t2_));
-                }
-                __syncthreads();
                 ASLAM_STAMP(3);
-                // S = Pt + R (ekf.cpp:300) -> lower tiles in LDS; padding rows/columns decouple (unit diagonal)
-                {
-                        const int ntl = nt * (nt + 1) / 2;
-                        for (int idx = tid; idx < ntl * 256; idx += SMALL_WG)
-                        {
-                                const int tl = idx >> 8, e = idx & 255;
-                                int ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
-                                while ((ib + 1) * (ib + 2) / 2 <= tl)
-                                        ++ib;
-                                while (ib * (ib + 1) / 2 > tl)
-                                        --ib;
-                                const int jb = tl - ib * (ib + 1) / 2;
-                                const int i = 16 * ib + (e >> 4), j = 16 * jb + (e & 15);
-                                double v = Pg[(size_t)i * NP + j];
-                                if (i == j)
-                                        v += (i < n) ? r_meas : 1.0;
-                                Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = v;
-                        }
-                }
-                __syncthreads();
                 ASLAM_STAMP(4);
-                // Kt = Pt S^-1 (rows of Pt are independent right-hand sides), u = Kt Y; r*Kt written back in place
-                #ifdef ASLAM_STAMPS
-                cholesky_solve_rows<NT>(Pg, Pg, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status,
-                                        (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr);
+                // Kt = Pt S^-1 with S = Pt + R (ekf.cpp:300-301): the rows of Pt are the right-hand sides, taken from the tiles before
+                // R goes onto their diagonal; u = Kt Y; the lower part of r*Kt (= (I - K H) P in measurement coordinates) returns to the tiles
+#ifdef ASLAM_STAMPS
+                cholesky_solve_rows<NT, true>(nullptr, nullptr, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status,
+                                              (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr, r_meas, n);
 #else
-                cholesky_solve_rows<NT>(Pg, Pg, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status);
+                cholesky_solve_rows<NT, true>(nullptr, nullptr, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status, nullptr, r_meas, n);
 #endif
                 ASLAM_STAMP(5);
                 __syncthreads();
@@ -197,31 +272,9 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                                 sX[tid] += sU[tid];
                 }
                 ASLAM_STAMP(7);
-                // P = (I - K H) P = H^-1 (r Kt) H^-T (ekf.cpp:310), in place: rows ...
-                for (int idx = tid; idx < nl * n; idx += SMALL_WG)
-                {
-                        const int i = idx / n, c = idx - i * n;
-                        const double *hc = sH + 8 * i;
-                        const double m0 = Pg[c], m1 = Pg[NP + c], m2 = Pg[2 * NP + c];
-                        double *ra = Pg + (size_t)(3 + 2 * i) * NP + c;
-                        const double ma = ra[0], mb = ra[NP] + m2;
-                        ra[0] = m0 - fma(hc[5], mb, hc[4] * ma);
-                        ra[NP] = m1 - fma(hc[7], mb, hc[6] * ma);
-                }
-                __syncthreads();
+                // P = (I - K H) P = H^-1 (r Kt) H^-T (ekf.cpp:310), in place on the tiles
+                congruence_tiles<false>(Lt, Dinv, sH, n, nl, tid);
                 ASLAM_STAMP(8);
-                // ... then columns
-                for (int idx = tid; idx < n * nl; idx += SMALL_WG)
-                {
-                        const int a = idx / nl, i = idx - a * nl;
-                        const double *hc = sH + 8 * i;
-                        double *row = Pg + (size_t)a * NP;
-                        const double w0 = row[0], w1 = row[1], w2 = row[2];
-                        const double wa = row[3 + 2 * i], wb = row[4 + 2 * i] + w2;
-                        row[3 + 2 * i] = w0 - fma(hc[5], wb, hc[4] * wa);
-                        row[4 + 2 * i] = w1 - fma(hc[7], wb, hc[6] * wa);
-                }
-                __syncthreads();
                 ASLAM_STAMP(9);
                 if (MODE == MODE_REPLAY)
                 {
@@ -237,6 +290,13 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 for (int i = 0; i < 12; ++i)
                         d.dbg[i] += stamp_acc[i];
 #endif
+        // P back to HBM, both triangles
+        __syncthreads();
+        for (int idx = tid; idx < NP * NP; idx += SMALL_WG)
+        {
+                const int i = idx / NP, j = idx - i * NP;
+                Pg[idx] = sym_get(Lt, i, j);
+        }
         small_store<MODE>(d, L, b, tid, NP);
 }
 } // namespace aslam
