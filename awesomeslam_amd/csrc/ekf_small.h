@@ -5,26 +5,31 @@
 
 namespace aslam
 {
-/// coefficient rows of landmark i acting on (p0, p1, p2, l_a, l_b): FWD = the two rows of H (updateH, ekf.cpp:117-134),
-/// otherwise the two rows of H^-1 (hc[4..7] = inverse of the landmark's 2x2 block)
-template <bool FWD> __device__ __forceinline__ void lm_coef(const double *hc, double (&C)[2][5])
+/// The two rows of T_i applied to a column (m0, m1, m2, ma, mb) of values indexed by (p0, p1, p2, l_a, l_b):
+///   FWD:  T_i = rows of H (updateH, ekf.cpp:117-134):   [h0 h1 0 -h0 -h1], [h2 h3 -1 -h2 -h3]       (c = hc[0..3])
+///   else: T_i = rows of H^-1:                            [1 0 -g1 -g0 -g1], [0 1 -g3 -g2 -g3]         (c = hc[4..7])
+template <bool FWD>
+__device__ __forceinline__ void lm_rows(const double *c, double m0, double m1, double m2, double ma, double mb, double &w0, double &w1)
 {
         if (FWD)
         {
-                C[0][0] = hc[0], C[0][1] = hc[1], C[0][2] = 0.0, C[0][3] = -hc[0], C[0][4] = -hc[1];
-                C[1][0] = hc[2], C[1][1] = hc[3], C[1][2] = -1.0, C[1][3] = -hc[2], C[1][4] = -hc[3];
+                const double d0 = m0 - ma, d1 = m1 - mb;
+                w0 = fma(c[1], d1, c[0] * d0);
+                w1 = fma(c[3], d1, c[2] * d0) - m2;
         }
         else
         {
-                C[0][0] = 1.0, C[0][1] = 0.0, C[0][2] = -hc[5], C[0][3] = -hc[4], C[0][4] = -hc[5];
-                C[1][0] = 0.0, C[1][1] = 1.0, C[1][2] = -hc[7], C[1][3] = -hc[6], C[1][4] = -hc[7];
+                const double e = mb + m2;
+                w0 = m0 - fma(c[1], e, c[0] * ma);
+                w1 = m1 - fma(c[3], e, c[2] * ma);
         }
 }
 
 /// P <- T P T^T on the symmetric P held as lower tiles in LDS, T = H (FWD) or H^-1.  T is the identity on the pose and
 /// couples landmark i only to the pose and to itself, so the 2x2 block (i, j) of the result needs the pose block, the pose
 /// columns of landmarks i and j and its own old value: after a side copy of the pose columns (`pose`: [n][3], LDS)
-/// every block is transformed in place by one thread, in one pass.  Ends with a barrier.
+/// every block is transformed in place by one thread, in one pass: W = T_i M (2 x 5, column by column), block = W T_j^T.
+/// Ends with a barrier.
 template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt, double *pose, const double *sH, int n, int nl, int tid)
 {
         for (int idx = tid; idx < 3 * n; idx += SMALL_WG)
@@ -38,21 +43,17 @@ template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt,
         {
                 if (w < nl)
                 {
-                        // landmark-pose block: rows 3+2i, 4+2i; columns 0..2
-                        const int i = w, ra = 3 + 2 * i;
-                        double C[2][5];
-                        lm_coef<FWD>(sH + 8 * i, C);
+                        // landmark-pose block: rows 3+2i, 4+2i; columns 0..2 = the first three columns of W
+                        const int ra = 3 + 2 * w;
+                        const double *ci = sH + 8 * w + (FWD ? 0 : 4);
 #pragma unroll
-                        for (int x = 0; x < 2; ++x)
-#pragma unroll
-                                for (int k = 0; k < 3; ++k)
-                                {
-                                        double v = C[x][3] * pose[3 * ra + k] + C[x][4] * pose[3 * (ra + 1) + k];
-#pragma unroll
-                                        for (int m = 0; m < 3; ++m)
-                                                v = fma(C[x][m], pose[3 * m + k], v);
-                                        *tile_elem(Lt, ra + x, k) = v;
-                                }
+                        for (int k = 0; k < 3; ++k)
+                        {
+                                double w0, w1;
+                                lm_rows<FWD>(ci, pose[k], pose[3 + k], pose[6 + k], pose[3 * ra + k], pose[3 * (ra + 1) + k], w0, w1);
+                                *tile_elem(Lt, ra, k) = w0;
+                                *tile_elem(Lt, ra + 1, k) = w1;
+                        }
                         continue;
                 }
                 const int q = w - nl;
@@ -63,51 +64,25 @@ template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt,
                         --i;
                 const int j = q - i * (i + 1) / 2; // j <= i
                 const int ra = 3 + 2 * i, ca = 3 + 2 * j;
-                double Ci[2][5], Cj[2][5];
-                lm_coef<FWD>(sH + 8 * i, Ci);
-                lm_coef<FWD>(sH + 8 * j, Cj);
-                // M: rows (p0, p1, p2, a_i, b_i) x columns (p0, p1, p2, a_j, b_j) of the old P
-                double M[5][5];
+                const double *ci = sH + 8 * i + (FWD ? 0 : 4), *cj = sH + 8 * j + (FWD ? 0 : 4);
+                // columns of M = old P over rows (p0, p1, p2, a_i, b_i); columns (p0, p1, p2, a_j, b_j)
+                double W0[5], W1[5];
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-                {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                                M[m][k] = pose[3 * m + k];
-                        M[m][3] = pose[3 * ca + m];
-                        M[m][4] = pose[3 * (ca + 1) + m];
-                        M[3][m] = pose[3 * ra + m];
-                        M[4][m] = pose[3 * (ra + 1) + m];
-                }
-                M[3][3] = *tile_elem(Lt, ra, ca);
-                M[4][3] = *tile_elem(Lt, ra + 1, ca);
-                M[4][4] = *tile_elem(Lt, ra + 1, ca + 1);
-                M[3][4] = (i == j) ? M[4][3] : *tile_elem(Lt, ra, ca + 1);
-                double W[2][5];
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int k = 0; k < 5; ++k)
-                        {
-                                double v = Ci[x][0] * M[0][k];
-#pragma unroll
-                                for (int m = 1; m < 5; ++m)
-                                        v = fma(Ci[x][m], M[m][k], v);
-                                W[x][k] = v;
-                        }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                        for (int y = 0; y < 2; ++y)
-                        {
-                                if (i == j && y > x)
-                                        continue; // the diagonal block is symmetric: lower entries only
-                                double v = W[x][0] * Cj[y][0];
-#pragma unroll
-                                for (int k = 1; k < 5; ++k)
-                                        v = fma(W[x][k], Cj[y][k], v);
-                                *tile_elem(Lt, ra + x, ca + y) = v;
-                        }
+                for (int k = 0; k < 3; ++k)
+                        lm_rows<FWD>(ci, pose[k], pose[3 + k], pose[6 + k], pose[3 * ra + k], pose[3 * (ra + 1) + k], W0[k], W1[k]);
+                double *e_aa = tile_elem(Lt, ra, ca), *e_ba = tile_elem(Lt, ra + 1, ca), *e_bb = tile_elem(Lt, ra + 1, ca + 1);
+                double *e_ab = (i == j) ? e_ba : tile_elem(Lt, ra, ca + 1);
+                lm_rows<FWD>(ci, pose[3 * ca], pose[3 * ca + 1], pose[3 * ca + 2], *e_aa, *e_ba, W0[3], W1[3]);
+                lm_rows<FWD>(ci, pose[3 * (ca + 1)], pose[3 * (ca + 1) + 1], pose[3 * (ca + 1) + 2], *e_ab, *e_bb, W0[4], W1[4]);
+                // block = W T_j^T: the rows of T_j applied to the rows of W
+                double o00, o01, o10, o11;
+                lm_rows<FWD>(cj, W0[0], W0[1], W0[2], W0[3], W0[4], o00, o01);
+                lm_rows<FWD>(cj, W1[0], W1[1], W1[2], W1[3], W1[4], o10, o11);
+                *e_aa = o00;
+                *e_ba = o10;
+                *e_bb = o11;
+                if (i != j)
+                        *e_ab = o01; // the diagonal block is symmetric: lower entries only
         }
         __syncthreads();
 }
@@ -124,7 +99,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                       *const sH = L.sH;
         SmallShared &sm = *L.sm;
 
-        const int tid = threadIdx.x;
+        const int tid_launch = threadIdx.x, tid = tid_launch;
         const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
         double *Pg = d.P + (size_t)b * NP * NP;
         const double r_meas = (double)KR, q_proc = (double)KQ;
@@ -151,6 +126,10 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
 
         for (int s = 0; s < nsteps; ++s)
         {
+                // hipcc hoists every tid-derived address of the ~20 loops below out of this loop and then spills them (150+ VGPRs,
+                // reloaded through scratch in every phase): an opaque re-definition per callback keeps them local to their phase
+                int tid = tid_launch;
+                asm volatile("" : "+v"(tid));
                 const int64_t t = t0 + s;
                 if (MODE == MODE_REPLAY)
                 {

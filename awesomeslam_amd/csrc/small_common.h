@@ -18,10 +18,13 @@
 // Cholesky factor and two triangular solves with n right-hand sides (2.33 n^3 flops instead of 18 n^3),
 // and H, H^-1, A are applied as the <=5-non-zeros-per-row operators they are.
 //
-// Data placement: P lives row-major in HBM/L2 (row stride NP = 16*NT doubles, zero padding) and is
-// transformed in place; S -> L and the inverted diagonal blocks live in LDS as 16x16 tiles; the
-// triangular solves keep a 16-row block of Pt^T per wave in MFMA accumulators (v_mfma_f64_16x16x4_f64),
-// taking L tiles from LDS as the A operand and the freshly solved tile, untouched, as the B operand.
+// Data placement (EKF): P is symmetric and lives in LDS for the whole launch as its lower 16x16 tiles (read from HBM,
+// row-major with row stride NP = 16*NT doubles and zero padding, once at launch start and written back at its end);
+// H P H^T and H^-1 (.) H^-T are one in-place block pass each on those tiles (ekf_small.h); the same tiles are then
+// factored in place (S = Pt + R -> L) next to the inverted diagonal blocks; the triangular solves keep a 16-row block of
+// Pt^T per wave in MFMA accumulators (v_mfma_f64_16x16x4_f64), taken from the tiles before they are factored, with L tiles
+// from LDS as the A operand and the freshly solved tile, untouched, as the B operand; the lower part of r*Kt returns to
+// the tiles.  (The UKF keeps P in HBM/L2 and only stages S -> L in the tiles: its LDS is taken by D / DZ slabs.)
 #pragma once
 
 #include "device_common.h"

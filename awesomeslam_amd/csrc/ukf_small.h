@@ -230,7 +230,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
         double *const stage = UL::STAGE_OVERLAYS_TILES ? Lt : reinterpret_cast<double *>(smem + UL::oStage);
         SmallShared &sm = *L.sm;
 
-        const int tid = threadIdx.x;
+        const int tid_launch = threadIdx.x, tid = tid_launch;
         const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
         const int MP = uv.MP;
         double *Pg = d.P + (size_t)b * NP * NP;
@@ -248,6 +248,9 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
 
         for (int s = 0; s < nsteps; ++s)
         {
+                // keep tid-derived addresses local to their phase instead of hoisted out of this loop and spilled (see ekf_small.h)
+                int tid = tid_launch;
+                asm volatile("" : "+v"(tid));
                 const int64_t t = t0 + s;
                 if (MODE == MODE_REPLAY)
                 {
@@ -303,7 +306,10 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         }
                 }
                 __syncthreads();
-                cholesky_lookahead<NT>(Lt, Dinv, nt, tid, &sm.status);
+                // (launch-time tid on purpose: with the opaque per-callback copy the NT = 2 instance of this call -- in effect the
+                // hand-pinned factor_diag_tile_fast inlined into it -- comes out 1e-6 off (bisected with per-phase variants,
+                // profiles/r01_experiments.md); every other phase, and the EKF's cholesky_solve_rows, are bit-for-bit unaffected)
+                cholesky_lookahead<NT>(Lt, Dinv, nt, tid_launch, &sm.status);
 
                 ASLAM_STAMP(1);
                 // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)
