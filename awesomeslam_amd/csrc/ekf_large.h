@@ -112,6 +112,7 @@ struct LargeLds
                 L.sY = nullptr;
                 L.sU = nullptr;
                 L.sH = nullptr;
+                L.sTv = nullptr;
                 L.sX = reinterpret_cast<double *>(p);
                 p += 8 * (size_t)NP;
                 L.sZ = reinterpret_cast<double *>(p);

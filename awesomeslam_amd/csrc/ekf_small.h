@@ -225,14 +225,9 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 ASLAM_STAMP(2);
                 ASLAM_STAMP(3);
                 ASLAM_STAMP(4);
-                // Kt = Pt S^-1 with S = Pt + R (ekf.cpp:300-301): the rows of Pt are the right-hand sides, taken from the tiles before
-                // R goes onto their diagonal; u = Kt Y; the lower part of r*Kt (= (I - K H) P in measurement coordinates) returns to the tiles
-#ifdef ASLAM_STAMPS
-                cholesky_solve_rows<NT, true>(nullptr, nullptr, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status,
-                                              (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr, r_meas, n);
-#else
-                cholesky_solve_rows<NT, true>(nullptr, nullptr, Lt, Dinv, nt, sY, sU, r_meas, tid, &sm.status, nullptr, r_meas, n);
-#endif
+                // S = Pt + R = L L^T (ekf.cpp:300); r*Kt = r I - r^2 S^-1 -> the tiles (= (I - K H) P in measurement coordinates,
+                // ekf.cpp:301,310); u = Kt Y = Y - r S^-1 Y
+                cholesky_inverse_tiles<NT>(Lt, Dinv, nt, n, sY, sU, L.sTv, r_meas, tid, &sm.status);
                 ASLAM_STAMP(5);
                 __syncthreads();
                 ASLAM_STAMP(6);

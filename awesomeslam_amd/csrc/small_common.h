@@ -130,7 +130,8 @@ template <int NT> struct SmallLayout
         static constexpr int oY = oZ + NP;
         static constexpr int oU = oY + NP;
         static constexpr int oH = oU + NP;           // per landmark: h00 h01 h10 h11 e00 e01 e10 e11
-        static constexpr int oEnd = oH + (NP / 2) * 8;
+        static constexpr int oTv = oH + (NP / 2) * 8; // scratch vector of the EKF's inverse-based update
+        static constexpr int oEnd = oTv + NP;
         // then floats / ints
         static constexpr size_t bytes_f64 = (size_t)oEnd * 8;
         static constexpr size_t oSr = bytes_f64;                       // float[OBS_CAP] range
@@ -795,6 +796,173 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
         __syncthreads();
 }
 
+/// EKF update in measurement coordinates when the tiles hold the symmetric P~ and R = r I (ekf.cpp:65,278):
+///     r Kt = r P~ S^-1 = r (S - r I) S^-1 = r I - r^2 S^-1,        Kt Y = Y - r S^-1 Y,        S = P~ + r I = L L^T
+/// so only the symmetric inverse S^-1 = L^-T L^-1 is needed: Cholesky (n^3/3), the forward substitution of the IDENTITY
+/// (its row blocks are triangular: n^3/3) and one triangular symmetric product (n^3/3) -- n^3 flops instead of the 2.33 n^3
+/// of factor + forward + backward on n right-hand sides, and no backward substitution at all.  The cancellation in
+/// r - r^2 (S^-1)_ii costs log10(r / P~_ii) digits (2-4 here), far inside the 1e-6 bar.
+/// In: tiles = P~ (lower).  Out: tiles = lower part of r Kt (zero padding), U = Kt Y.  Same three wave roles and look-ahead
+/// as cholesky_solve_rows; `Tv`: LDS scratch of 16*NT doubles.  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv, int nt, int n_true, const double *Y, double *U,
+                                                       double *Tv, double r, int tid, uint32_t *status)
+{
+        static_assert(NT + 1 < SMALL_WAVES, "row-block waves, the diagonal wave and at least one helper");
+        constexpr int DW = NT;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int li = lane & 15, lg = lane >> 4;
+        if (tid < 16 * nt)
+                *tile_elem(Lt, tid, tid) += (tid < n_true) ? r : 1.0; // S = P~ + R; padding decouples
+        __syncthreads();
+        if (wave < nt)
+        {
+                const int rb = wave;
+                // right-hand side = rows 16 rb .. of the identity, in the transposed accumulator layout
+                d4 acc[NT];
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                                acc[cb][q] = (cb == rb && li == lg + 4 * q) ? 1.0 : 0.0;
+                __syncthreads(); // (the diagonal wave factors tile 0)
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        if (kb >= rb) // block columns left of the diagonal block of this row block stay zero
+                                forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
+                        chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        __syncthreads();
+                }
+                // acc = rows of L^-T; L is dead: its tiles take L^-1 (tile (cb, rb) = transpose of block (rb, cb) of L^-T)
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb)
+                {
+                        if (cb >= rb && cb < nt)
+                        {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                        Lt[tile_index(cb, rb) * TSZ + (lg + 4 * q) * TLD + li] = acc[cb][q];
+                        }
+                }
+                __syncthreads(); // [A] L^-1 complete
+                // (S^-1)(rb, jb) = sum_{k >= rb} Linv(k, rb)^T Linv(k, jb) for jb <= rb, in registers
+#pragma unroll
+                for (int jb = 0; jb < NT; ++jb)
+                {
+                        if (jb <= rb)
+                        {
+                                d4 o = {0.0, 0.0, 0.0, 0.0};
+                                for (int k = rb; k < nt; ++k)
+                                {
+                                        const double *A = Lt + tile_index(k, rb) * TSZ, *B = Lt + tile_index(k, jb) * TSZ;
+                                        double a[4], bq[4];
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                        {
+                                                a[q] = A[(lg + 4 * q) * TLD + li];
+                                                bq[q] = B[(lg + 4 * q) * TLD + li];
+                                        }
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                                o = mfma_f64(a[q], bq[q], o);
+                                }
+                                acc[jb] = o; // C layout: element (row lg + 4 q, column li) of the tile
+                        }
+                }
+                __syncthreads(); // [B] nobody reads L^-1 any more
+                const double r2 = r * r;
+#pragma unroll
+                for (int jb = 0; jb < NT; ++jb)
+                {
+                        if (jb <= rb)
+                        {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                {
+                                        const int i = 16 * rb + lg + 4 * q, j = 16 * jb + li;
+                                        if (j <= i)
+                                        {
+                                                double v = 0.0;
+                                                if (i < n_true) // (j <= i < n)
+                                                        v = ((i == j) ? r : 0.0) - r2 * acc[jb][q];
+                                                Lt[tile_index(rb, jb) * TSZ + (lg + 4 * q) * TLD + li] = v;
+                                        }
+                                }
+                        }
+                }
+        }
+        else if (wave == DW)
+        {
+                __builtin_amdgcn_s_setprio(3);
+                bool ok = factor_diag_tile_fast(Lt, Dinv, lane);
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        ok = chol_lookahead(Lt, Dinv, nt, kb, lane, li, lg) && ok;
+                        __syncthreads();
+                }
+                if (!ok && lane == 0)
+                        *status |= 4u; // ASLAM_ST_NOT_PD
+                __builtin_amdgcn_s_setprio(0);
+                __syncthreads(); // [A]
+                __syncthreads(); // [B]
+        }
+        else
+        {
+                __syncthreads();
+                for (int kb = 0; kb < nt; ++kb)
+                {
+                        chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        __syncthreads();
+                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        __syncthreads();
+                }
+                __syncthreads(); // [A]
+                if (wave == DW + 1)
+                {
+                        // U = Kt Y = Y - r S^-1 Y with S^-1 Y = Linv^T (Linv Y): two triangular tile mat-vecs by this one wave
+                        for (int ib = 0; ib < nt; ++ib)
+                        {
+                                double p = 0.0;
+                                for (int jb = 0; jb <= ib; ++jb)
+                                {
+                                        const double *Tt = Lt + tile_index(ib, jb) * TSZ;
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                                p = fma(Tt[li * TLD + lg + 4 * q], Y[16 * jb + lg + 4 * q], p);
+                                }
+                                p += __shfl_xor(p, 16);
+                                p += __shfl_xor(p, 32);
+                                if (lg == 0)
+                                        Tv[16 * ib + li] = p;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (int jb = 0; jb < nt; ++jb)
+                        {
+                                double p = 0.0;
+                                for (int ib = jb; ib < nt; ++ib)
+                                {
+                                        const double *Tt = Lt + tile_index(ib, jb) * TSZ;
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                                p = fma(Tt[(lg + 4 * q) * TLD + li], Tv[16 * ib + lg + 4 * q], p);
+                                }
+                                p += __shfl_xor(p, 16);
+                                p += __shfl_xor(p, 32);
+                                if (lg == 0)
+                                        U[16 * jb + li] = Y[16 * jb + li] - r * p;
+                        }
+                }
+                __syncthreads(); // [B]
+        }
+        __syncthreads();
+}
+
 /// Cholesky factorisation of the tile matrix alone (Lt -> L, Dinv -> inverted diagonal blocks), same look-ahead
 /// scheme as cholesky_solve_rows: wave NT factors diagonal tile kb+1 while the others update the trailing tiles.
 template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt, double *Dinv, int nt, int tid, uint32_t *status)
@@ -926,7 +1094,7 @@ __device__ __forceinline__ void solve_row_block(const double *Src, double *Dst, 
 /// LDS pointers of one workgroup (carved by SmallLayout)
 struct SmallLds
 {
-        double *Lt, *Dinv, *sX, *sZ, *sY, *sU, *sH;
+        double *Lt, *Dinv, *sX, *sZ, *sY, *sU, *sH, *sTv;
         float *sSr, *sSb, *sPx, *sPy, *sMd;
         int *sCid;
         float *sWr, *sWb, *sWx, *sWy;
@@ -950,6 +1118,7 @@ template <int NT> __device__ __forceinline__ SmallLds small_carve(unsigned char 
         L.sY = lds + LY::oY;
         L.sU = lds + LY::oU;
         L.sH = lds + LY::oH;
+        L.sTv = lds + LY::oTv;
         L.sSr = reinterpret_cast<float *>(smem + LY::oSr);
         L.sSb = reinterpret_cast<float *>(smem + LY::oSb);
         L.sPx = reinterpret_cast<float *>(smem + LY::oPx);
