@@ -392,53 +392,6 @@ __device__ __forceinline__ bool factor_diag_tile_fast(double *T, double *Ti, int
         return ok;
 }
 
-/// As load_row_block, from a SYMMETRIC matrix held as lower tiles in LDS (columns right of the diagonal tile come from the
-/// transposed tiles below it; inside the diagonal tile the lower triangle is the valid one)
-template <int NT> __device__ __forceinline__ void load_row_block_tiles(d4 (&acc)[NT], const double *Lt, int rb, int nt, int lane)
-{
-        const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt)
-                {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                                const int cl = lg + 4 * r;
-                                double v;
-                                if (cb < rb)
-                                        v = Lt[tile_index(rb, cb) * TSZ + li * TLD + cl];
-                                else if (cb > rb)
-                                        v = Lt[tile_index(cb, rb) * TSZ + cl * TLD + li];
-                                else
-                                        v = (cl <= li) ? Lt[tile_index(rb, rb) * TSZ + li * TLD + cl] : Lt[tile_index(rb, rb) * TSZ + cl * TLD + li];
-                                acc[cb][r] = v;
-                        }
-                }
-        }
-}
-
-/// lower part of the row block in acc, times scale, back into the lower tiles
-template <int NT> __device__ __forceinline__ void store_row_block_tiles(const d4 (&acc)[NT], double *Lt, int rb, int nt, double scale, int lane)
-{
-        const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt && cb <= rb)
-                {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                                const int cl = lg + 4 * r;
-                                if (cb < rb || cl <= li)
-                                        Lt[tile_index(rb, cb) * TSZ + li * TLD + cl] = acc[cb][r] * scale;
-                        }
-                }
-        }
-}
-
 /// Load the 16 rows [16 rb, 16 rb + 16) of Src (row-major, stride NP) into MFMA accumulator layout, transposed:
 /// acc[cb][r] of lane l = Src[16 rb + (l&15)][16 cb + (l>>4) + 4 r].
 template <int NT> __device__ __forceinline__ void load_row_block(d4 (&acc)[NT], const double *Src, int rb, int nt, int lane)
@@ -599,7 +552,7 @@ __device__ __forceinline__ bool chol_lookahead(double *Lt, double *Dinv, int nt,
 
 /// Backward substitution on the row block held in acc: acc <- (acc^T L^-1)^T, then u[row] = result . Y and
 /// Dst[rows] = scale * result.  One wave; operands of a whole block step are fetched before its MFMAs.
-template <int NT, bool STORE = true>
+template <int NT>
 __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int rb, int nt, const double *Lt, const double *Dinv,
                                                const double *Y, double *U, double scale, int lane)
 {
@@ -647,7 +600,7 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
                 }
         }
         double part = 0.0;
-        double *outp = STORE ? Dst + (size_t)(16 * rb + li) * NP + lg : nullptr;
+        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
 #pragma unroll
         for (int cb = 0; cb < NT; ++cb)
         {
@@ -657,8 +610,7 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
                         for (int r = 0; r < 4; ++r)
                         {
                                 part = fma(acc[cb][r], Y[16 * cb + lg + 4 * r], part);
-                                if (STORE)
-                                        outp[16 * cb + 4 * r] = acc[cb][r] * scale;
+                                outp[16 * cb + 4 * r] = acc[cb][r] * scale;
                         }
                 }
         }
@@ -677,14 +629,10 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
 ///     and the forward step of block column kb, so the serial 16x16 factorisations leave the critical path;
 ///   * the remaining waves only help with panel / trailing tiles.
 /// Ends with a barrier.
-///
-/// TILES_IO (EKF, P resident in LDS): the tiles hold the symmetric right-hand side P~ itself.  The row-block waves take their
-/// rows from the tiles, then `diag_add` (R) goes onto the true diagonal (1 on the padding diagonal) and the tiles are
-/// factored in place; the lower part of scale * (P~ S^-1) goes back into the tiles.  Src / Dst are not used; n_true = N.
-template <int NT, bool TILES_IO = false>
+template <int NT>
 __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
                                                     const double *Y, double *U, double scale, int tid, uint32_t *status,
-                                                    unsigned long long *wave_busy = nullptr, double diag_add = 0.0, int n_true = 0)
+                                                    unsigned long long *wave_busy = nullptr)
 {
 #ifdef ASLAM_STAMPS
         unsigned long long tb_[3] = {0, 0, 0}, tm_ = __builtin_amdgcn_s_memtime(), tn_;
@@ -699,16 +647,7 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
         if (wave < nt)
         {
                 d4 acc[NT];
-                if (TILES_IO)
-                {
-                        load_row_block_tiles<NT>(acc, Lt, wave, nt, lane);
-                        __syncthreads(); // every right-hand side is in registers
-                        if (tid < 16 * nt)
-                                *tile_elem(Lt, tid, tid) += (tid < n_true) ? diag_add : 1.0; // S = P~ + R; padding decouples
-                        __syncthreads();
-                }
-                else
-                        load_row_block<NT>(acc, Src, wave, nt, lane);
+                load_row_block<NT>(acc, Src, wave, nt, lane);
                 __syncthreads(); // (the diagonal wave factors tile 0)
                 for (int kb = 0; kb < nt; ++kb)
                 {
@@ -723,23 +662,11 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
-                if (TILES_IO)
-                {
-                        backward_store<NT, false>(acc, nullptr, wave, nt, Lt, Dinv, Y, U, scale, lane);
-                        __syncthreads(); // nobody reads L any more
-                        store_row_block_tiles<NT>(acc, Lt, wave, nt, scale, lane);
-                }
-                else
-                        backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
+                backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
                 WB(2);
         }
         else if (wave == DW)
         {
-                if (TILES_IO)
-                {
-                        __syncthreads();
-                        __syncthreads();
-                }
                 // the diagonal wave is the critical path and shares its SIMD with two MFMA-heavy waves: let it win issue arbitration
                 __builtin_amdgcn_s_setprio(3);
                 bool ok = factor_diag_tile_fast(Lt, Dinv, lane);
@@ -759,16 +686,9 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
                 __builtin_amdgcn_s_setprio(0);
-                if (TILES_IO)
-                        __syncthreads();
         }
         else
         {
-                if (TILES_IO)
-                {
-                        __syncthreads();
-                        __syncthreads();
-                }
                 __syncthreads();
                 for (int kb = 0; kb < nt; ++kb)
                 {
@@ -782,8 +702,6 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
-                if (TILES_IO)
-                        __syncthreads();
         }
 #ifdef ASLAM_STAMPS
         if (wave_busy && lane == 0)
