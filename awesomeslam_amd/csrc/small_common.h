@@ -14,9 +14,10 @@
 // ekf.cpp:61,65,276,278), Pt = H P H^T, S = Pt + r I = L L^T, Kt = Pt S^-1:
 //     K = P H^T S^-1 = H^-1 Kt          ->  X += H^-1 (Kt Y)
 //     (I - K H) P    = H^-1 (r Kt) H^-T
-// which is algebraically identical to ekf.cpp:300-310 (no symmetry of P is assumed) but needs only a
-// Cholesky factor and two triangular solves with n right-hand sides (2.33 n^3 flops instead of 18 n^3),
-// and H, H^-1, A are applied as the <=5-non-zeros-per-row operators they are.
+// which is algebraically identical to ekf.cpp:300-310 and needs at most a Cholesky factor and two triangular
+// solves with n right-hand sides (2.33 n^3 flops instead of 18 n^3); H, H^-1, A are applied as the
+// <=5-non-zeros-per-row operators they are.  With R = r I and P symmetric it is cheaper still:
+//     r Kt = r I - r^2 S^-1,   Kt Y = Y - r S^-1 Y          (cholesky_inverse_tiles: ~n^3 flops, no backward solve)
 //
 // Data placement (EKF): P is symmetric and lives in LDS for the whole launch as its lower 16x16 tiles (read from HBM,
 // row-major with row stride NP = 16*NT doubles and zero padding, once at launch start and written back at its end);

@@ -220,7 +220,9 @@ def main():
                          "hbm": None if traffic is None else {"achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                                               "frac": traffic / kernel_s / 1e9 / PEAK_HBM_GBPS},
                          "kernel_ms": kernel_s * 1e3,
-                         "note": "achieved = SURVEY 8(d) algorithmic flops/callback x callbacks x trajectories per launch / "
+                         "note": "achieved = SURVEY 8(d) algorithmic flops/callback (EKF 2.33 n^3, UKF 10.7 n^3: the reference-equivalent "
+                                 "minimum the survey defines; the single-CU EKF kernel itself executes about n^3 since its update "
+                                 "uses R = r I) x callbacks x trajectories per launch / "
                                  "mean launch duration (HIP events on the launch stream); peak = dense "
                                  + ("fp32" if large else "fp64") + " MFMA rate (MI355X_MICROARCH.md)"},
         }
