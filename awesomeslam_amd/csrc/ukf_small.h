@@ -68,7 +68,8 @@ enum
 /// of LDS.  Output tiles are dealt round-robin to the waves (<= TPW per wave).
 template <int NT, int MODE, bool SKIP_K0 = false>
 __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int ld, int nks, const double *w, int nt,
-                                          double *Cg, double *Ct, double diag_add, int n_true, double *stage, int tid)
+                                          double *Cg, double *Ct, double diag_add, int n_true, double *stage, int tid,
+                                          const double *gvec = nullptr, double gscale = 0.0)
 {
         typedef UkfLayout<NT> UL;
         constexpr int NP = UL::NP, LD = UL::SLAB_LD, SLAB = UL::SLAB;
@@ -201,8 +202,8 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                                 }
                                 else if (MODE == GEMM_STORE)
                                         Cg[(size_t)i * NP + j] = acc[q][r];
-                                else
-                                        Cg[(size_t)i * NP + j] -= acc[q][r];
+                                else // GEMM_SUBTRACT, with an optional rank-one term gscale * g g^T (g: LDS, zero beyond the true dimension)
+                                        Cg[(size_t)i * NP + j] -= gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r];
                         }
                 }
         }
@@ -370,9 +371,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 // ---- predicted mean, ukf.cpp:300-304.  Pose rows: the weighted sum over all sigma points, in the reference's
                 // order.  Landmark rows are affine in the sigma points, the +- pairs cancel, and sum_i w_i x_i(k) = (sum_i w_i) X(k)
                 // exactly (the sum of the binary32 weights is not 1: that factor is part of the reference's arithmetic).
-                double wsum = w_0;
-                for (int i = 1; i < m; ++i)
-                        wsum += w_i;
+                const double wsum = fma((double)(m - 1), w_i, w_0); // w_0 + (m - 1) w_i: the m - 1 equal weights summed in one step
                 for (int k = tid; k < NP; k += SMALL_WG)
                 {
                         double acc = 0.0;
@@ -627,16 +626,24 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 ASLAM_STAMP(8);
                 for (int j = tid; j < NP; j += SMALL_WG)
                         sVv[j] = (j < 16 * nt) ? Kg[(size_t)n * NP + j] : 0.0;
-                for (int a = tid; a < NP; a += SMALL_WG)
+                // g = K+ z: one wave per row, lanes along the row (coalesced), reduced across the wave
                 {
-                        double g = 0.0;
-                        if (a < n)
+                        const int lane = tid & 63, wave = tid >> 6;
+                        for (int a = wave; a < NP; a += SMALL_WG / 64)
                         {
-                                const double *row = Kg + (size_t)a * NP;
-                                for (int j = 0; j < n; ++j)
-                                        g = fma(row[j], sZv[j], g);
+                                double g = 0.0;
+                                if (a < n)
+                                {
+                                        const double *row = Kg + (size_t)a * NP;
+                                        for (int j = lane; j < n; j += 64)
+                                                g = fma(row[j], sZv[j], g);
+                                }
+#pragma unroll
+                                for (int o = 1; o < 64; o <<= 1)
+                                        g += __shfl_xor(g, o);
+                                if (lane == 0)
+                                        sGv[a] = g;
                         }
-                        sGv[a] = g;
                 }
                 __syncthreads();
                 {
@@ -646,30 +653,39 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                 Tcg[(size_t)n * NP + j] = 0.0;
                                 Kg[(size_t)n * NP + j] = 0.0;
                         }
+                        // z.v and v.y: the same sums in every wave
                         double zv = 0.0, vy = 0.0;
-                        for (int j = 0; j < n; ++j)
+                        for (int j = (tid & 63); j < n; j += 64)
                         {
                                 zv = fma(sZv[j], sVv[j], zv);
                                 vy = fma(sVv[j], sY[j], vy);
                         }
-                        const double inv_den = 1.0 / (1.0 - zv);
-                        // K = K+ + g v^T / (1 - z^T v)  (ukf.cpp:378), u = K Zdiff
-                        for (int idx = tid; idx < n * n; idx += SMALL_WG)
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1)
                         {
-                                const int a = idx / n, j = idx - a * n;
-                                Kg[(size_t)a * NP + j] += sGv[a] * inv_den * sVv[j];
+                                zv += __shfl_xor(zv, o);
+                                vy += __shfl_xor(vy, o);
+                        }
+                        const double inv_den = 1.0 / (1.0 - zv);
+                        // K = K+ + g v^T / (1 - z^T v)  (ukf.cpp:378) is never completed: u = K Zdiff = u+ + g (v.y) / (1 - z.v), and
+                        // K S K^T = Tc K^T = Tc K+^T + (Tc v) g^T / (1 - z.v) with Tc v = Tc S+^-1 z = K+ z = g: a rank-one term that rides in
+                        // the write-out of the GEMM below
+                        __syncthreads();
+                        for (int a = tid; a < NP; a += SMALL_WG)
+                        {
+                                if (a < n)
+                                        sU[a] += sGv[a] * inv_den * vy;
+                                else
+                                        sGv[a] = 0.0;
                         }
                         __syncthreads();
-                        for (int a = tid; a < n; a += SMALL_WG)
-                                sU[a] += sGv[a] * inv_den * vy;
+                        ASLAM_STAMP(9);
+                        // ---- X = X + K Zdiff (ukf.cpp:389)
+                        for (int k = tid; k < n; k += SMALL_WG)
+                                sX[k] = sXbar[k] + sU[k];
+                        // ---- P = P - K S K^T (ukf.cpp:391) = P - Tc K+^T - g g^T / (1 - z.v)
+                        gemm_wabt<NT, GEMM_SUBTRACT>(Tcg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
                 }
-                __syncthreads();
-                ASLAM_STAMP(9);
-                // ---- X = X + K Zdiff (ukf.cpp:389)
-                for (int k = tid; k < n; k += SMALL_WG)
-                        sX[k] = sXbar[k] + sU[k];
-                // ---- P = P - K S K^T (ukf.cpp:391): K S = Tc, so (K S) K^T = Tc K^T
-                gemm_wabt<NT, GEMM_SUBTRACT>(Tcg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid);
 
                 ASLAM_STAMP(10);
                 if (MODE == MODE_REPLAY)
