@@ -938,6 +938,15 @@ int aslam_debug_stamps(aslam_ctx *c, unsigned long long *out12)
         return ASLAM_OK;
 }
 
+/* diagnostic builds only (-DASLAM_FE_STAMPS): front-end phase cycles, 6 values */
+int aslam_debug_fe_stamps(aslam_ctx *c, unsigned long long *out6)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        HIP_TRY(hipMemcpy(out6, c->dv.dbg + 45, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
 /* diagnostic builds only: per-wave busy cycles inside cholesky_forward: [wave][panel, trailing/forward/factor] */
 int aslam_debug_wave_busy(aslam_ctx *c, unsigned long long *out24)
 {

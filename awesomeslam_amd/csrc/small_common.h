@@ -96,7 +96,7 @@ struct DevView
                 if (tid == 0 && blockIdx.x == 0)                                                                       \
                 {                                                                                                      \
                         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
-                        d.dbg[i] += now_ - fe_last;                                                                    \
+                        d.dbg[40 + (i)] += now_ - fe_last;   /* slots 45..50: clear of the kernels' phase stamps (0..11) and wave counters (16..39) */                                                                    \
                         fe_last = now_;                                                                                \
                 }                                                                                                      \
         } while (0)
