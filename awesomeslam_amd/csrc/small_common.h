@@ -621,6 +621,91 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
                 U[16 * rb + li] = part;
 }
 
+/// Forward-only tail of the fused solve (UKF): the row block in acc is W = Src L^-T.  Store it, and let the wave that owns
+/// row `qrow` publish that row (q^T) to LDS.
+template <int NT> __device__ __forceinline__ void forward_store(const d4 (&acc)[NT], double *Dst, int rb, int nt, int qrow, double *Q, int lane)
+{
+        constexpr int NP = 16 * NT;
+        const int li = lane & 15, lg = lane >> 4;
+        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
+        const bool mine = (16 * rb + li == qrow);
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb)
+        {
+                if (cb < nt)
+                {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                outp[16 * cb + 4 * r] = acc[cb][r];
+                                if (mine)
+                                        Q[16 * cb + lg + 4 * r] = acc[cb][r];
+                        }
+                }
+        }
+}
+
+/// U[row] = W[row] . T and G[row] = W[row] . Q for the 16 rows of the block held in acc (T, Q: LDS vectors)
+template <int NT>
+__device__ __forceinline__ void row_dots(const d4 (&acc)[NT], int rb, int nt, const double *T, const double *Q, double *U, double *G, int lane)
+{
+        const int li = lane & 15, lg = lane >> 4;
+        double pu = 0.0, pg = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb)
+        {
+                if (cb < nt)
+                {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                pu = fma(acc[cb][r], T[16 * cb + lg + 4 * r], pu);
+                                pg = fma(acc[cb][r], Q[16 * cb + lg + 4 * r], pg);
+                        }
+                }
+        }
+        pu += __shfl_xor(pu, 16);
+        pu += __shfl_xor(pu, 32);
+        pg += __shfl_xor(pg, 16);
+        pg += __shfl_xor(pg, 32);
+        if (lg == 0)
+        {
+                U[16 * rb + li] = pu;
+                G[16 * rb + li] = pg;
+        }
+}
+
+/// T = L^-1 Y for a vector (LDS), tile by tile, by ONE wave: T_kb = Linv(kb) (Y_kb - sum_{j<kb} L(kb,j) T_j)
+__device__ __forceinline__ void forward_vector(const double *Lt, const double *Dinv, int nt, const double *Y, double *T, int lane)
+{
+        const int li = lane & 15, lg = lane >> 4;
+        for (int kb = 0; kb < nt; ++kb)
+        {
+                double p = 0.0;
+                for (int j = 0; j < kb; ++j)
+                {
+                        const double *Lkj = Lt + tile_index(kb, j) * TSZ;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                                p = fma(Lkj[li * TLD + lg + 4 * s], T[16 * j + lg + 4 * s], p);
+                }
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                const double r = Y[16 * kb + li] - p; // every lane of row li holds it
+                const double *Di = Dinv + kb * TSZ;
+                double q = 0.0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                        q = fma(Di[li * TLD + lg + 4 * s], __shfl(r, lg + 4 * s), q);
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                if (lg == 0)
+                        T[16 * kb + li] = q;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // the next block reads T through LDS
+        }
+}
+
 /// Dst = scale * Src S^-1 for all rows (Src, Dst row-major HBM with stride NP, may alias; S = lower tiles in Lt, which
 /// leaves as its Cholesky factor), u = (Src S^-1) Y.  The whole workgroup takes part, in three wave roles that
 /// run their own loops with the same barrier sequence (so that each role gets its own register allocation):
@@ -630,10 +715,14 @@ __device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int r
 ///     and the forward step of block column kb, so the serial 16x16 factorisations leave the critical path;
 ///   * the remaining waves only help with panel / trailing tiles.
 /// Ends with a barrier.
-template <int NT>
+///
+/// FWD_ONLY (UKF): no backward substitution.  Dst = W = Src L^-T, Tv = L^-1 Y, Qv = row `qrow` of W, U = W Tv, G = W Qv
+/// (Tv, Qv, G: LDS vectors of 16*NT doubles): all a symmetric update P -= W W^T + rank one needs.
+template <int NT, bool FWD_ONLY = false>
 __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
                                                     const double *Y, double *U, double scale, int tid, uint32_t *status,
-                                                    unsigned long long *wave_busy = nullptr)
+                                                    unsigned long long *wave_busy = nullptr, double *Tv = nullptr, double *Qv = nullptr,
+                                                    double *G = nullptr, int qrow = -1)
 {
 #ifdef ASLAM_STAMPS
         unsigned long long tb_[3] = {0, 0, 0}, tm_ = __builtin_amdgcn_s_memtime(), tn_;
@@ -663,7 +752,14 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
-                backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
+                if (FWD_ONLY)
+                {
+                        forward_store<NT>(acc, Dst, wave, nt, qrow, Qv, lane);
+                        __syncthreads(); // Qv and Tv (diagonal wave) are in LDS
+                        row_dots<NT>(acc, wave, nt, Tv, Qv, U, G, lane);
+                }
+                else
+                        backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
                 WB(2);
         }
         else if (wave == DW)
@@ -686,6 +782,11 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
+                if (FWD_ONLY)
+                {
+                        forward_vector(Lt, Dinv, nt, Y, Tv, lane);
+                        __syncthreads();
+                }
                 __builtin_amdgcn_s_setprio(0);
         }
         else
@@ -703,6 +804,8 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
+                if (FWD_ONLY)
+                        __syncthreads();
         }
 #ifdef ASLAM_STAMPS
         if (wave_busy && lane == 0)

@@ -621,70 +621,47 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         Tcg[(size_t)n * NP + j] = sZv[j];
                 __syncthreads();
                 ASLAM_STAMP(7);
-                // ---- K+ = Tc S+^-1 (and v^T = z^T S+^-1 in row n), u+ = K+ Zdiff: fused Cholesky + row-block solves
-                cholesky_solve_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, 1.0, tid, &sm.status);
+                // ---- S+ = L L^T, W = Tc L^-T (and q^T = z^T L^-T in row n), t = L^-1 Zdiff, u = W t, g = W q: fused Cholesky +
+                // forward substitution of the row blocks.  With S^-1 = S+^-1 + v v^T / (1 - z^T v), v = S+^-1 z = L^-T q (Sherman-Morrison):
+                //   K Zdiff  = Tc S^-1 Zdiff  = W t + g (q.t) / (1 - q.q)
+                //   K S K^T  = Tc S^-1 Tc^T   = W W^T + g g^T / (1 - q.q)
+                // so neither K nor a backward substitution is needed (ukf.cpp:378-391 evaluated in this form).
+                double *const sT = sZpred, *const sQ = sVv; // both dead by now
+                cholesky_solve_rows<NT, true>(Tcg, Kg, Lt, Dinv, nt, sY, sU, 1.0, tid, &sm.status, nullptr, sT, sQ, sGv, n);
                 ASLAM_STAMP(8);
-                for (int j = tid; j < NP; j += SMALL_WG)
-                        sVv[j] = (j < 16 * nt) ? Kg[(size_t)n * NP + j] : 0.0;
-                // g = K+ z: one wave per row, lanes along the row (coalesced), reduced across the wave
                 {
-                        const int lane = tid & 63, wave = tid >> 6;
-                        for (int a = wave; a < NP; a += SMALL_WG / 64)
+                        // q.q and q.t: the same sums in every wave
+                        double qq = 0.0, qt = 0.0;
+                        for (int j = (tid & 63); j < n; j += 64)
                         {
-                                double g = 0.0;
-                                if (a < n)
-                                {
-                                        const double *row = Kg + (size_t)a * NP;
-                                        for (int j = lane; j < n; j += 64)
-                                                g = fma(row[j], sZv[j], g);
-                                }
-#pragma unroll
-                                for (int o = 1; o < 64; o <<= 1)
-                                        g += __shfl_xor(g, o);
-                                if (lane == 0)
-                                        sGv[a] = g;
+                                qq = fma(sQ[j], sQ[j], qq);
+                                qt = fma(sQ[j], sT[j], qt);
                         }
-                }
-                __syncthreads();
-                {
-                        // the padding row goes back to zero before anything else reads Tc / K
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1)
+                        {
+                                qq += __shfl_xor(qq, o);
+                                qt += __shfl_xor(qt, o);
+                        }
+                        const double inv_den = 1.0 / (1.0 - qq);
+                        __syncthreads();
+                        // the padding row goes back to zero before anything else reads Tc / W
                         for (int j = tid; j < 16 * nt; j += SMALL_WG)
                         {
                                 Tcg[(size_t)n * NP + j] = 0.0;
                                 Kg[(size_t)n * NP + j] = 0.0;
                         }
-                        // z.v and v.y: the same sums in every wave
-                        double zv = 0.0, vy = 0.0;
-                        for (int j = (tid & 63); j < n; j += 64)
-                        {
-                                zv = fma(sZv[j], sVv[j], zv);
-                                vy = fma(sVv[j], sY[j], vy);
-                        }
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1)
-                        {
-                                zv += __shfl_xor(zv, o);
-                                vy += __shfl_xor(vy, o);
-                        }
-                        const double inv_den = 1.0 / (1.0 - zv);
-                        // K = K+ + g v^T / (1 - z^T v)  (ukf.cpp:378) is never completed: u = K Zdiff = u+ + g (v.y) / (1 - z.v), and
-                        // K S K^T = Tc K^T = Tc K+^T + (Tc v) g^T / (1 - z.v) with Tc v = Tc S+^-1 z = K+ z = g: a rank-one term that rides in
-                        // the write-out of the GEMM below
-                        __syncthreads();
-                        for (int a = tid; a < NP; a += SMALL_WG)
-                        {
-                                if (a < n)
-                                        sU[a] += sGv[a] * inv_den * vy;
-                                else
-                                        sGv[a] = 0.0;
-                        }
-                        __syncthreads();
-                        ASLAM_STAMP(9);
                         // ---- X = X + K Zdiff (ukf.cpp:389)
-                        for (int k = tid; k < n; k += SMALL_WG)
-                                sX[k] = sXbar[k] + sU[k];
-                        // ---- P = P - K S K^T (ukf.cpp:391) = P - Tc K+^T - g g^T / (1 - z.v)
-                        gemm_wabt<NT, GEMM_SUBTRACT>(Tcg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
+                        for (int k = tid; k < NP; k += SMALL_WG)
+                        {
+                                if (k < n)
+                                        sX[k] = sXbar[k] + sU[k] + sGv[k] * (qt * inv_den);
+                                else
+                                        sGv[k] = 0.0;
+                        }
+                        ASLAM_STAMP(9);
+                        // ---- P = P - K S K^T (ukf.cpp:391) = P - W W^T - g g^T / (1 - q.q)
+                        gemm_wabt<NT, GEMM_SUBTRACT>(Kg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
                 }
 
                 ASLAM_STAMP(10);
