@@ -1,37 +1,42 @@
 #!/usr/bin/env python
 """bench.py -- filter-steps/s of the MI355X-native EKF/UKF-SLAM core on synthetic trajectories.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ekf64|ukf64|ekf8] [--batch B] [--chunk C]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ekf512|ekf64|ukf64|ekf8] [--batch B] [--chunk C]
+                    [--scaling weak|strong --trajectories M] [--no-sub]
 
-One bench "step" = one replay launch = `chunk` consecutive callbacks (sensor message + odom message:
-association, growth bookkeeping, predict, update) for each of the `batch` independent trajectories held by a
-GPU.  The trace is already resident in HBM when the timed region starts.  With --gpus N (launched by
-torch.distributed.run, one rank per GPU) every rank owns `batch` trajectories of its own (weak scaling) and the
-only communication is one all_gather of the pose streams at the end of the timed region.
+Default workload: BASELINE.json configs[3] -- EKF, 512 landmarks (n = 1027), fp32 MFMA products, 256 trajectories per GPU
+(the north-star configuration; the largest one that fits a single GPU).  On one GPU the same JSON line carries the
+configs[1] (ekf64) and configs[2] (ukf64) measurements as sub-records, each with its own roofline.
+
+One bench "step" = one replay launch = `chunk` consecutive callbacks (sensor message + odom message: association, growth
+bookkeeping, predict, update) for each of the `batch` independent trajectories held by a GPU.  The trace is already resident
+in HBM when the timed region starts.
+
+--gpus N: one process per GPU.  Under torch.distributed.run the ranks are taken from the environment; started plainly
+(`python bench.py --gpus N`, WORLD_SIZE unset) this process spawns the N rank processes itself, before it touches the GPU.
+--scaling weak (default): every rank owns `batch` trajectories of its own.  --scaling strong --trajectories M: M trajectories
+in total (configs[4]: 8), dealt to the ranks in contiguous blocks.  Either way the only communication is one all_gather of the
+pose streams at the end of the timed region (RCCL over xGMI).
+
 Prints ONE JSON line (rank 0).  The CPU oracle is used for the `cpu_baseline` leg and for nothing else.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from awesomeslam_amd import dist as adist  # noqa: E402
-from awesomeslam_amd import trace as tg  # noqa: E402
-from awesomeslam_amd.core import Core  # noqa: E402
-
 WORKLOADS = {
     # name: (filter, landmarks, BASELINE.json config it corresponds to)
+    "ekf512": ("ekf", 512, "configs[3]: EKF, 512 landmarks (n=1027), fp32 MFMA products, multi-workgroup launch chain"),
     "ekf64": ("ekf", 64, "configs[1]: EKF, 64 landmarks (n=131), fp64"),
     "ukf64": ("ukf", 64, "configs[2]: UKF, 64 landmarks (n=131), fp64"),
     "ekf8": ("ekf", 8, "configs[0] geometry on the GPU: EKF, 8 landmarks (n=19), fp64"),
-    "ekf512": ("ekf", 512, "configs[3]/[4]: EKF, 512 landmarks (n=1027), fp32 covariance, multi-workgroup launch chain"),
 }
 # fp32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_16x16x4_f32 at the vector rate)
 PEAK_F32_TFLOPS = 157.3
@@ -39,6 +44,8 @@ PEAK_F32_TFLOPS = 157.3
 # (= half of the 157.3 TFLOP/s FP32 row of MI355X_MICROARCH.md, which lists no fp64 row of its own)
 PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
+UKF_MAX_CALLBACKS = 3000  # the reference UKF stays positive definite for a few thousand callbacks at n = 131
+PROLOGUE = 64  # callbacks: the 42-callback warm-up in which the state grows to its full dimension, rounded up
 
 
 def algorithmic_flops(kind, n):
@@ -46,31 +53,85 @@ def algorithmic_flops(kind, n):
     return (2.0 + 1.0 / 3.0) * n ** 3 if kind == "ekf" else 10.7 * n ** 3
 
 
-def cpu_baseline(kind, L, seed, prologue, sample):
+def executed_flops(workload, n):
+    """Flops the kernels actually issue per callback (padded tiles, structure-blind products), from the launch geometry."""
+    if workload == "ekf512":
+        nb = (n + 1 + 63) // 64  # 64-blocks of the stacked matrix [S; G; Y^T]
+        f = 0.0
+        for k in range(nb):
+            blocks = 2 * nb - k - 1  # row blocks below the diagonal block: rest of S, all of G
+            f += blocks * 2.0 * 64 * 64 * (64 * k)  # left-looking history
+            f += blocks * 2.0 * 64 * 64 * 64  # C Linv^T
+            f += (nb - k - 1) * 2.0 * 64 * 64 * 64  # diagonal blocks of S, right-looking
+            f += 2.0 * 64 ** 3 * (1.0 / 3.0 + 1.0 / 3.0)  # in-register potrf + inverse
+        nt = (nb * 64 + 127) // 128
+        f += (nt * (nt + 1) // 2 - nt * 0.25) * 2.0 * 128 * 128 * (nb * 64)  # syrk lower tiles (upper quadrant of diagonal ones idle)
+        return f
+    np_ = 16 * ((n + 15) // 16)
+    if workload in ("ekf64", "ekf8"):
+        return 1.0 * np_ ** 3  # Cholesky + inverse of L + L^-T L^-1 on 16x16 tiles, n^3/3 each (DESIGN.md section 4)
+    return algorithmic_flops("ukf", np_)  # the UKF kernel exploits the same structure the survey's figure assumes
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh children, nothing in this process has
+    touched the GPU), relay rank 0's line, exit with the worst return code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3000
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                rc = rc or code
+        if rc or time.time() > deadline:
+            for p in pending:  # a rank failed: the others would wait in a collective for ever
+                p.kill()
+            rc = rc or 1
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def cpu_baseline(kind, L, seed, sample):
     """The C++ oracle (Eigen-free restatement of the reference node, -O2, one core) on a bounded sample of the
     same workload: trajectory 0, `sample` steady-state callbacks after the warm-up prologue."""
     from oracle.cpu_bench import run
 
-    r = run(kind, L, seed, 0, prologue, sample)
+    r = run(kind, L, seed, 0, PROLOGUE, sample)
     el = r["t1"] - r["t0"]
     if L >= 256:
         what = (f"{sample} slam() calls on a synthetic state of the same dimension N={r['N']} (no warm-up: a callback takes "
                 f"seconds); oracle/aslam_oracle.cpp (as-coded 18 n^3 dense algebra, fp64), g++ -O2, 1 thread, {el:.1f} s")
     else:
-        what = (f"trajectory 0 of the same seed, {sample} steady-state callbacks after a {prologue}-callback "
+        what = (f"trajectory 0 of the same seed, {sample} steady-state callbacks after a {PROLOGUE}-callback "
                 f"warm-up, N={r['N']}; oracle/aslam_oracle.cpp (as-coded 18 n^3 algebra), g++ -O2, 1 thread, {el:.1f} s")
     return {"value": sample / el, "unit": "filter-steps/s", "cores": 1, "kind": "port", "sample": what}
 
 
-def cpu_baseline_all_cores(kind, L, seed, prologue, sample):
+def cpu_baseline_all_cores(kind, L, seed, sample):
     """the reference node is single-threaded, so "all cores" = one trajectory per host core, one oracle
     process each (oracle/cpu_bench.py), same bounded sample per process; value = sum of the per-process rates."""
-    import subprocess
-
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
     cmd = [sys.executable, "-m", "oracle.cpu_bench", "--kind", kind, "--landmarks", str(L), "--seed", str(seed),
-           "--prologue", str(prologue), "--sample", str(sample)]
+           "--prologue", str(PROLOGUE), "--sample", str(sample)]
     procs = [subprocess.Popen(cmd + ["--traj", str(b)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for b in range(cores)]
     res = []
@@ -89,22 +150,35 @@ def cpu_baseline_all_cores(kind, L, seed, prologue, sample):
                       f"and overlap for {max(overlap, 0.0):.1f} s"}
 
 
-def single_trajectory_latency(kind, L, seed, prologue, C1, large, local, dev):
-    """batch 1 is reported with every number.  One filter alone on the GPU, `C1` steady-state callbacks in one
-    launch (replay seam), HIP events on the launch stream; the second of two launches is reported."""
-    from awesomeslam_amd.core import F32, F64
-    tr = tg.make_traces(L, prologue + 2 * C1, B=1, seed=seed)
-    core = Core(kind, tg.dim_cap(L), batch=1, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
+def make_core(workload, B, tr, local):
+    from awesomeslam_amd import trace as tg
+    from awesomeslam_amd.core import Core, F32, F64
+
+    kind, L, _ = WORKLOADS[workload]
+    large = workload == "ekf512"
+    return Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
                 dtype=F32 if large else F64)
+
+
+def single_trajectory_latency(workload, seed, C1, local, dev):
+    """batch 1 is reported with every number (it is also the shape configs[4] runs at with one trajectory per
+    GPU).  One filter alone on the GPU, `C1` steady-state callbacks in one launch (replay seam), HIP events on the launch
+    stream; the second of two launches is reported."""
+    import torch
+    from awesomeslam_amd import trace as tg
+
+    kind, L, _ = WORKLOADS[workload]
+    tr = tg.make_traces(L, PROLOGUE + 2 * C1, B=1, seed=seed)
+    core = make_core(workload, 1, tr, local)
     core.set_trace(tr)
     stream = torch.cuda.current_stream().cuda_stream
-    scratch = torch.zeros((1, max(C1, prologue), 3), dtype=torch.float64, device=dev)
-    core.replay(0, prologue, scratch.data_ptr(), None, stream)
+    scratch = torch.zeros((1, max(C1, PROLOGUE), 3), dtype=torch.float64, device=dev)
+    core.replay(0, PROLOGUE, scratch.data_ptr(), None, stream)
     ms = []
     for w in range(2):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        core.replay(prologue + w * C1, C1, scratch.data_ptr(), None, stream)
+        core.replay(PROLOGUE + w * C1, C1, scratch.data_ptr(), None, stream)
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
@@ -114,60 +188,36 @@ def single_trajectory_latency(kind, L, seed, prologue, C1, large, local, dev):
             "filter_steps_per_s": C1 / (ms[1] * 1e-3), "steady_state": bool(ok)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ekf64", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default 256)")
-    ap.add_argument("--chunk", type=int, default=None,
-                    help="callbacks per launch (= per bench step); default 500 (EKF) / 200 (UKF: the reference UKF only stays "
-                         "positive definite for a few thousand callbacks at n = 131, DESIGN.md)")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=None, help="callbacks timed on the CPU oracle (0 = skip)")
-    args = ap.parse_args()
+def measure(workload, B, C, K, W, seed, first_traj, rank, world, local, dev):
+    """W untimed + exactly K timed replay launches of `C` callbacks for this rank's `B` trajectories; barrier + synchronize on
+    both sides of the timed region, one all_gather of the pose streams at its end, max over ranks of the elapsed time.
+    Returns (elapsed_s, mean launch duration by HIP events in s, kernel info, trace_gen_s)."""
+    import numpy as np
+    import torch
+    from awesomeslam_amd import dist as adist
+    from awesomeslam_amd import trace as tg
 
-    rank, world, local = adist.init()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the filter core has no CPU fallback")
-    local = local % torch.cuda.device_count()  # ranks share devices only in the gloo rehearsal (ASLAM_DIST_BACKEND=gloo)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    kind, L, cfg_name = WORKLOADS[args.workload]
+    kind, L, _ = WORKLOADS[workload]
     n_full = tg.full_dim(L)
-    large = args.workload == "ekf512"
-    if args.chunk is None:
-        args.chunk = 20 if large else 200 if kind == "ukf" else 500
-    if args.batch is None:
-        args.batch = 256
-    B, C, K, W = args.batch, args.chunk, args.steps, args.warmup
-    prologue = 64  # callbacks: the 42-callback warm-up in which the state grows to n_full, rounded up
-    T = prologue + (W + K) * C
-
-    # ---- synthetic input, distinct per trajectory and per rank, resident in HBM before timing starts
+    T = PROLOGUE + (W + K) * C
     t_gen = time.time()
-    tr = tg.make_traces(L, T, B=B, seed=args.seed, first_traj=rank * B)
+    tr = tg.make_traces(L, T, B=B, seed=seed, first_traj=first_traj)
     t_gen = time.time() - t_gen
-    from awesomeslam_amd.core import F32, F64
-    core = Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
-                dtype=F32 if large else F64)
+    core = make_core(workload, B, tr, local)
     core.set_trace(tr)
+    del tr
     stream = torch.cuda.current_stream().cuda_stream
     poses = torch.zeros((K, B, C, 3), dtype=torch.float64, device=dev)
-    scratch = torch.zeros((B, max(C, prologue), 3), dtype=torch.float64, device=dev)
-    dims = torch.zeros((B, prologue), dtype=torch.int32, device=dev)
+    scratch = torch.zeros((B, max(C, PROLOGUE), 3), dtype=torch.float64, device=dev)
 
-    core.replay(0, prologue, scratch.data_ptr(), dims.data_ptr(), stream)
+    core.replay(0, PROLOGUE, scratch.data_ptr(), None, stream)
     torch.cuda.synchronize()
-    for b in range(0, B, max(1, B // 8)):
+    probe = range(0, B, max(1, B // 8))
+    for b in probe:
         if core.dim(b) != n_full or core.status(b) != 0:
             raise SystemExit(f"trajectory {b}: N={core.dim(b)} (want {n_full}), status={core.status(b)} after the warm-up")
     for w in range(W):
-        core.replay(prologue + w * C, C, scratch.data_ptr(), None, stream)
+        core.replay(PROLOGUE + w * C, C, scratch.data_ptr(), None, stream)
     adist.gather_poses(scratch[:, :1])  # the collective once, untimed: communicator and buffers exist when the clock starts
     torch.cuda.synchronize()
 
@@ -178,65 +228,144 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         ev[k][0].record()
-        core.replay(prologue + (W + k) * C, C, poses[k].data_ptr(), None, stream)
+        core.replay(PROLOGUE + (W + k) * C, C, poses[k].data_ptr(), None, stream)
         ev[k][1].record()
     all_poses = adist.gather_poses(poses.permute(1, 0, 2, 3).reshape(B, K * C, 3))  # the one collective: poses, at the end
     torch.cuda.synchronize()
     adist.barrier()
     el = time.perf_counter() - t0
     el = adist.max_over_ranks(el, dev if world > 1 else "cpu")
-    launch_ms = [a.elapsed_time(b) for a, b in ev]
-    kernel_s = float(np.mean(launch_ms)) * 1e-3
+    kernel_s = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
-    ok = all(core.dim(b) == n_full and core.status(b) == 0 for b in range(0, B, max(1, B // 8)))
+    ok = all(core.dim(b) == n_full and core.status(b) == 0 for b in probe)
     finite = bool(torch.isfinite(all_poses).all().item())
     if not (ok and finite):
-        raise SystemExit("bench: a filter left its steady state (dimension/status/non-finite pose)")
+        raise SystemExit(f"bench {workload}: a filter left its steady state (dimension/status/non-finite pose)")
+    info = core.kernel_info()
+    core.close()
+    del poses, scratch, all_poses
+    torch.cuda.empty_cache()
+    return el, kernel_s, info, t_gen
+
+
+def roofline(workload, B, C, kernel_s):
+    from awesomeslam_amd import trace as tg
+
+    kind, L, _ = WORKLOADS[workload]
+    n = tg.full_dim(L)
+    large = workload == "ekf512"
+    peak = PEAK_F32_TFLOPS if large else PEAK_F64_TFLOPS
+    achieved = algorithmic_flops(kind, n) * B * C / kernel_s / 1e12
+    executed = executed_flops(workload, n) * B * C / kernel_s / 1e12
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj):
+        try:
+            ent = json.load(open(tj)).get(workload, {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            if traffic is not None and ent.get("trajectories") and ent.get("callbacks_per_launch"):
+                # the PMC passes are per launch of the shape they were taken at: scale to this launch's callbacks x trajectories
+                traffic = traffic * (B * C) / (ent["trajectories"] * ent["callbacks_per_launch"])
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "executed_frac": executed / peak, "traffic": traffic,
+            # the other roofline north_star asks for: PMC bytes at the L2's memory side per launch / launch time
+            "hbm": None if traffic is None else {"achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                                 "frac": traffic / kernel_s / 1e9 / PEAK_HBM_GBPS},
+            "kernel_ms": kernel_s * 1e3,
+            "note": "achieved = SURVEY 8(d) algorithmic flops per callback (EKF 2.33 n^3, UKF 10.7 n^3: the reference-equivalent "
+                    "minimum the survey defines) x callbacks x trajectories per launch / mean launch duration (HIP events on the "
+                    "launch stream); executed_frac = the same with the flops the kernels really issue (padded tiles; the single-CU EKF "
+                    "update needs only S^-1 since R = r I: about n^3); peak = dense " + ("fp32" if large else "fp64")
+                    + " MFMA rate (MI355X_MICROARCH.md); traffic = PMC bytes at the L2's memory side (profiles/pmc_traffic.json)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ekf512", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (weak scaling; default 256)")
+    ap.add_argument("--chunk", type=int, default=None,
+                    help="callbacks per launch (= per bench step); default 20 (ekf512) / 500 (EKF) / 200 (UKF, capped so that a "
+                         "run stays within the 3000 callbacks the reference UKF survives)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--trajectories", type=int, default=8, help="total trajectories under --scaling strong (configs[4]: 8)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="callbacks timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-sub", action="store_true", help="skip the ekf64 / ukf64 sub-records")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    import torch
+    from awesomeslam_amd import dist as adist
+    from awesomeslam_amd import trace as tg
+
+    rank, world, local = adist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the filter core has no CPU fallback")
+    local = local % torch.cuda.device_count()  # ranks share devices only in the gloo rehearsal (ASLAM_DIST_BACKEND=gloo)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    wl = args.workload
+    kind, L, cfg_name = WORKLOADS[wl]
+    n_full = tg.full_dim(L)
+    large = wl == "ekf512"
+    K, W = args.steps, args.warmup
+    C = args.chunk if args.chunk is not None else (20 if large else 200 if kind == "ukf" else 500)
+    if kind == "ukf":
+        C = max(1, min(C, (UKF_MAX_CALLBACKS - PROLOGUE) // (K + W)))
+    if args.scaling == "strong":
+        if args.trajectories % world:
+            raise SystemExit(f"--trajectories {args.trajectories} does not divide over {world} ranks")
+        B = args.trajectories // world
+        cfg_name = cfg_name.replace("configs[3]", "configs[4]") + f"; {args.trajectories} trajectories in total"
+    else:
+        B = args.batch if args.batch is not None else 256
+    first_traj = rank * B
+
+    el, kernel_s, info, t_gen = measure(wl, B, C, K, W, args.seed, first_traj, rank, world, local, dev)
 
     if rank == 0:
         total_steps = world * B * C * K
-        flops_launch = algorithmic_flops(kind, n_full) * B * C
-        achieved = flops_launch / kernel_s / 1e12
-        peak = PEAK_F32_TFLOPS if large else PEAK_F64_TFLOPS
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        info = core.kernel_info()
         out = {
             "metric": "EKF/UKF filter-steps/s @ N_landmarks", "value": total_steps / el, "unit": "filter-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if large else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} = {cfg_name}", "landmarks": L, "state_dim": n_full,
-                       "trajectories_per_gpu": B, "callbacks_per_step": C, "parallelism": f"trajectory-sharded x{world}",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if large else "f64", "data": "synthetic",
+            "config": {"workload": f"{wl} = {cfg_name}", "landmarks": L, "state_dim": n_full,
+                       "trajectories_per_gpu": B, "trajectories_total": world * B, "callbacks_per_step": C,
+                       "parallelism": f"trajectory-sharded x{world}",
                        "kernel": info["name"], "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
                        "trace_gen_s": round(t_gen, 1)},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         # the other roofline north_star asks for: PMC bytes at the L2's memory side per launch / launch time
-                         "hbm": None if traffic is None else {"achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                                              "frac": traffic / kernel_s / 1e9 / PEAK_HBM_GBPS},
-                         "kernel_ms": kernel_s * 1e3,
-                         "note": "achieved = SURVEY 8(d) algorithmic flops/callback (EKF 2.33 n^3, UKF 10.7 n^3: the reference-equivalent "
-                                 "minimum the survey defines; the single-CU EKF kernel itself executes about n^3 since its update "
-                                 "uses R = r I) x callbacks x trajectories per launch / "
-                                 "mean launch duration (HIP events on the launch stream); peak = dense "
-                                 + ("fp32" if large else "fp64") + " MFMA rate (MI355X_MICROARCH.md)"},
+            "roofline": roofline(wl, B, C, kernel_s),
         }
         if world == 1:
-            out["single_trajectory"] = single_trajectory_latency(kind, L, args.seed, prologue, min(C, 200), large, local, dev)
-        sample = args.cpu_sample
-        if sample is None:
-            sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000, "ekf512": 3}[args.workload]
-        if world == 1 and sample > 0:
-            out["cpu_baseline"] = cpu_baseline(kind, L, args.seed, prologue, sample)
-            allc = cpu_baseline_all_cores(kind, L, args.seed, prologue, sample)
-            if allc:
-                out["cpu_baseline_all_cores"] = allc
-        print(json.dumps(out))
+            out["single_trajectory"] = single_trajectory_latency(wl, args.seed, min(C, 200), local, dev)
+            if wl == "ekf512" and args.scaling == "weak" and not args.no_sub:
+                # configs[1] and configs[2] on the same clock, as sub-records (fixed shapes, whatever --steps/--warmup say)
+                out["sub"] = {}
+                for sw, sC, sK, sW in (("ekf64", 500, 4, 1), ("ukf64", 200, 6, 2)):
+                    sel, sks, sinfo, _ = measure(sw, 256, sC, sK, sW, args.seed, 0, 0, 1, local, dev)
+                    skind, sL, sname = WORKLOADS[sw]
+                    out["sub"][sw] = {"value": 256 * sC * sK / sel, "unit": "filter-steps/s", "dtype": "f64", "workload": f"{sw} = {sname}",
+                                      "trajectories_per_gpu": 256, "callbacks_per_step": sC, "steps": sK, "warmup": sW,
+                                      "ms_per_step": sel / sK * 1e3, "kernel": sinfo["name"], "roofline": roofline(sw, 256, sC, sks)}
+            sample = args.cpu_sample
+            if sample is None:
+                sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000, "ekf512": 3}[wl]
+            if sample > 0:
+                out["cpu_baseline"] = cpu_baseline(kind, L, args.seed, sample)
+                allc = cpu_baseline_all_cores(kind, L, args.seed, sample)
+                if allc:
+                    out["cpu_baseline_all_cores"] = allc
+        print(json.dumps(out), flush=True)
     adist.finalize()
 
 
