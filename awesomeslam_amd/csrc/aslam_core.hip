@@ -64,6 +64,7 @@ struct aslam_ctx
         LargeView<double> lv64 = {};
         LargeView<float> lv32 = {};
         int *skipped = nullptr;
+        double *largeP = nullptr; // = lv64.P or lv32.P: the covariance is binary64 in both modes
         // replay splits the batch into groups that run the launch chain side by side on separate streams: the latency-bound
         // launches of one group (one-wave diagonal factorisations, the front end, short-K panels) then overlap the GEMMs of
         // the others
@@ -97,20 +98,13 @@ int upload_P(aslam_ctx *c, int traj, int n, const double *P)
                         std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
                 HIP_TRY(hipMemcpy(c->dv.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
         }
-        else if (c->cfg.dtype == ASLAM_F32)
-        {
-                std::vector<float> v(NP * NP, 0.f);
-                for (int i = 0; i < n; ++i)
-                        for (int j = 0; j < n; ++j)
-                                v[(size_t)i * NP + j] = (float)P[(size_t)i * n + j];
-                HIP_TRY(hipMemcpy(c->lv32.P + traj * NP * NP, v.data(), sizeof(float) * NP * NP, hipMemcpyHostToDevice));
-        }
         else
         {
+                // the large path keeps P in binary64 in both modes (fp32 mode: binary32 G, S, L, V and MFMA products)
                 std::vector<double> v(NP * NP, 0.0);
                 for (int i = 0; i < n; ++i)
                         std::memcpy(&v[(size_t)i * NP], P + (size_t)i * n, sizeof(double) * n);
-                HIP_TRY(hipMemcpy(c->lv64.P + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(c->largeP + traj * NP * NP, v.data(), sizeof(double) * NP * NP, hipMemcpyHostToDevice));
         }
         return ASLAM_OK;
 }
@@ -118,16 +112,7 @@ int upload_P(aslam_ctx *c, int traj, int n, const double *P)
 int download_P(aslam_ctx *c, int traj, int n, double *P)
 {
         const size_t NP = (size_t)c->NP;
-        if (c->large && c->cfg.dtype == ASLAM_F32)
-        {
-                std::vector<float> v((size_t)n * NP);
-                HIP_TRY(hipMemcpy(v.data(), c->lv32.P + traj * NP * NP, sizeof(float) * n * NP, hipMemcpyDeviceToHost));
-                for (int i = 0; i < n; ++i)
-                        for (int j = 0; j < n; ++j)
-                                P[(size_t)i * n + j] = (double)v[(size_t)i * NP + j];
-                return ASLAM_OK;
-        }
-        const double *src = c->large ? c->lv64.P : c->dv.P;
+        const double *src = c->large ? c->largeP : c->dv.P;
         HIP_TRY(hipMemcpy2D(P, sizeof(double) * n, src + traj * NP * NP, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost));
         return ASLAM_OK;
 }
@@ -138,19 +123,10 @@ int grow_P_rows(aslam_ctx *c, int traj, int n_old, int n_new)
         const size_t NP = (size_t)c->NP;
         for (int i = n_old; i < n_new; ++i)
         {
-                if (c->large && c->cfg.dtype == ASLAM_F32)
-                {
-                        std::vector<float> row(NP, 0.f);
-                        row[i] = (float)KP_LANDMARK_POSE;
-                        HIP_TRY(hipMemcpy(c->lv32.P + traj * NP * NP + (size_t)i * NP, row.data(), sizeof(float) * NP, hipMemcpyHostToDevice));
-                }
-                else
-                {
-                        std::vector<double> row(NP, 0.0);
-                        row[i] = (double)KP_LANDMARK_POSE;
-                        double *dst = (c->large ? c->lv64.P : c->dv.P) + traj * NP * NP + (size_t)i * NP;
-                        HIP_TRY(hipMemcpy(dst, row.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
-                }
+                std::vector<double> row(NP, 0.0);
+                row[i] = (double)KP_LANDMARK_POSE;
+                double *dst = (c->large ? c->largeP : c->dv.P) + traj * NP * NP + (size_t)i * NP;
+                HIP_TRY(hipMemcpy(dst, row.data(), sizeof(double) * NP, hipMemcpyHostToDevice));
         }
         return ASLAM_OK;
 }
@@ -173,14 +149,14 @@ int sync_ctx(aslam_ctx *c)
 template <typename T> int init_P_large(aslam_ctx *c, LargeView<T> &lv)
 {
         const size_t B = c->cfg.batch, NP = c->NP;
-        HIP_TRY(hipMemset(lv.P, 0, sizeof(T) * B * NP * NP));
+        HIP_TRY(hipMemset(lv.P, 0, sizeof(double) * B * NP * NP));
         HIP_TRY(hipMemset(lv.G, 0, sizeof(T) * B * NP * NP));
         HIP_TRY(hipMemset(lv.S, 0, sizeof(T) * B * NP * NP));
-        std::vector<T> blk(3 * NP, (T)0);
+        std::vector<double> blk(3 * NP, 0.0);
         for (int i = 0; i < 3; ++i)
-                blk[(size_t)i * NP + i] = (T)(double)KP_ROBOT_POSE;
+                blk[(size_t)i * NP + i] = (double)KP_ROBOT_POSE;
         for (size_t b = 0; b < B; ++b)
-                HIP_TRY(hipMemcpy(lv.P + b * NP * NP, blk.data(), sizeof(T) * blk.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(lv.P + b * NP * NP, blk.data(), sizeof(double) * blk.size(), hipMemcpyHostToDevice));
         return ASLAM_OK;
 }
 
@@ -317,7 +293,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 g.v.G += b * np * np;
                 g.v.S += b * np * np;
                 g.v.Hc += b * (np / 2) * 4;
-                g.v.Linv += b * LB * LB;
+                g.v.Linv += b * LARGE_NB_MAX * LB * LB;
                 g.v.Y += b * np;
                 g.skip += b;
                 return g;
@@ -326,14 +302,30 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
                 hipLaunchKernelGGL(large_build_GS<T>, dim3(2 + NP / 2, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
-                for (int k = 0; k < NB; ++k)
-                {
-                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
-                        hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, g.skip);
-                }
                 const int ntile = (NP + 127) / 128;
-                hipLaunchKernelGGL(large_syrk<T>, dim3(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8)), dim3(256), 0, g.st, g.dv, g.v, gb,
-                                   g.skip);
+                const dim3 syrk_grid(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8));
+                if constexpr (sizeof(T) == 4)
+                {
+                        // binary32: Cholesky of S alone (17 x {diagonal block, panel of S}), then V = G L^-T with the solved columns
+                        // resident in registers (one launch), then P -= V V^T into the fp64 covariance
+                        for (int k = 0; k < NB; ++k)
+                        {
+                                hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                                if (k + 1 < NB)
+                                        hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
+                        }
+                        hipLaunchKernelGGL(large_trsm_resident<LARGE_NB_MAX>, dim3(NB, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                        hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                }
+                else
+                {
+                        for (int k = 0; k < NB; ++k)
+                        {
+                                hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                                hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 0, g.skip);
+                        }
+                        hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                }
                 hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
                                    g.dims, g.skip);
         };
@@ -507,21 +499,23 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                 {
                         c->lv32.NP = c->NP;
                         A_(dev_alloc(c, &c->lv32.P, B * NP * NP, c->owned));
+                        c->largeP = c->lv32.P;
                         A_(dev_alloc(c, &c->lv32.G, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv32.S, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv32.Hc, B * (NP / 2) * 4, c->owned));
                         A_(dev_alloc(c, &c->lv32.Y, B * NP, c->owned));
-                        A_(dev_alloc(c, &c->lv32.Linv, B * LB * LB, c->owned));
+                        A_(dev_alloc(c, &c->lv32.Linv, B * LARGE_NB_MAX * LB * LB, c->owned));
                 }
                 else
                 {
                         c->lv64.NP = c->NP;
                         A_(dev_alloc(c, &c->lv64.P, B * NP * NP, c->owned));
+                        c->largeP = c->lv64.P;
                         A_(dev_alloc(c, &c->lv64.G, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv64.S, B * NP * NP, c->owned));
                         A_(dev_alloc(c, &c->lv64.Hc, B * (NP / 2) * 4, c->owned));
                         A_(dev_alloc(c, &c->lv64.Y, B * NP, c->owned));
-                        A_(dev_alloc(c, &c->lv64.Linv, B * LB * LB, c->owned));
+                        A_(dev_alloc(c, &c->lv64.Linv, B * LARGE_NB_MAX * LB * LB, c->owned));
                 }
         }
         A_(dev_alloc(c, &d.A, B * 2, c->owned));
@@ -1057,12 +1051,16 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
 {
         if (!c)
                 return fail(ASLAM_ERR_ARG, "null context");
-        char buf[96];
+        char buf[128];
         size_t lds = 0;
         if (c->large)
         {
-                std::snprintf(buf, sizeof(buf), "large_update_panel<%s> (%d-launch chain per callback, %d stream groups)",
-                              c->cfg.dtype == ASLAM_F32 ? "float" : "double", 4 + 2 * (c->NP / LB), c->large_groups);
+                if (c->cfg.dtype == ASLAM_F32)
+                        std::snprintf(buf, sizeof(buf), "large_trsm_resident<%d> + large_syrk_f32p64 (%d-launch chain per callback, %d stream groups)",
+                                      (int)LARGE_NB_MAX, 4 + 2 * (c->NP / LB), c->large_groups);
+                else
+                        std::snprintf(buf, sizeof(buf), "large_update_panel<double> (%d-launch chain per callback, %d stream groups)",
+                                      4 + 2 * (c->NP / LB), c->large_groups);
                 lds = LargeLds::bytes(c->NP);
         }
         else if (c->cfg.filter == ASLAM_EKF)

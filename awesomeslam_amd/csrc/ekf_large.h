@@ -33,16 +33,17 @@ constexpr int LB = 64;               // block size of the factorisation = GEMM t
 constexpr int LARGE_OBS_CAP = 1024;  // stored sensor message (LDS)
 constexpr int LARGE_WAIT_CAP = 2048; // wait-list (LDS)
 constexpr int LARGE_NP_MAX = 1088;   // 17 blocks of 64: n <= 1087
+constexpr int LARGE_NB_MAX = LARGE_NP_MAX / LB;
 
 template <typename T> struct LargeView
 {
         int NP;     // row stride, multiple of LB
-        T *P;       // [B][NP][NP]
+        double *P;  // [B][NP][NP]  always binary64 (fp32 mode: only G, S, L, V and the MFMA products are binary32)
         T *G;       // [B][NP][NP]  P H^T, then V; row n carries Y^T, then (L^-1 Y)^T
         T *S;       // [B][NP][NP]  innovation covariance, then L (lower)
         double *Hc; // [B][NP/2][4] h00 h01 h10 h11 per landmark
         double *Y;  // [B][NP]
-        T *Linv;    // [B][LB][LB]  inverse of the diagonal block of L being eliminated
+        T *Linv;    // [B][LARGE_NB_MAX][LB][LB]  inverses of the diagonal blocks of L
 };
 
 // ---- MFMA traits -------------------------------------------------------------------------------------------------
@@ -156,8 +157,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         double *const sX = L.sX, *const sZ = L.sZ;
         const int tid = threadIdx.x;
         const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
-        T *Pg = lv.P + (size_t)b * NP * NP;
-        T *Gg = lv.G + (size_t)b * NP * NP;
+        double *Pg = lv.P + (size_t)b * NP * NP;
         double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
         double *Yg = lv.Y + (size_t)b * NP;
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         ASLAM_STAMP(0);
         if (MODE == MODE_REPLAY)
         {
-                if (small_frontend<true, LARGE_OBS_CAP, LARGE_WAIT_CAP, LARGE_NP_MAX / 2, T>(d, L, Pg, NP, b, t, s, nsteps, poses_out,
+                if (small_frontend<true, LARGE_OBS_CAP, LARGE_WAIT_CAP, LARGE_NP_MAX / 2, double>(d, L, Pg, NP, b, t, s, nsteps, poses_out,
                                                                                                dims_out, tid))
                 {
                         if (tid == 0)
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         ASLAM_STAMP(2);
         // P <- A P A^T + Q (ekf.cpp:297), A = I except A(0,0), A(1,0): rows 0,1 then columns 0,1
         {
-                const T a00 = (T)sm.a00, a10 = (T)sm.a10, q = (T)(double)KQ;
+                const double a00 = sm.a00, a10 = sm.a10, q = (double)KQ;
                 for (int c = tid; c < n; c += SMALL_WG)
                 {
-                        const T r0 = Pg[c];
+                        const double r0 = Pg[c];
                         Pg[c] = a00 * r0;
                         Pg[NP + c] = a10 * r0 + Pg[NP + c];
                 }
                 __syncthreads();
                 for (int r = tid; r < n; r += SMALL_WG)
                 {
-                        T *row = Pg + (size_t)r * NP;
-                        const T c0 = row[0];
-                        T v0 = a00 * c0, v1 = a10 * c0 + row[1];
+                        double *row = Pg + (size_t)r * NP;
+                        const double c0 = row[0];
+                        double v0 = a00 * c0, v1 = a10 * c0 + row[1];
                         if (r == 0)
                                 v0 += q;
                         if (r == 1)
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
                                 row[2] += q;
                 }
         }
-        (void)Gg;
         ASLAM_STAMP(3);
         small_store<MODE>(d, L, b, tid, NP);
         ASLAM_STAMP(4);
@@ -268,7 +267,9 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
 /// owns two consecutive rows (a landmark pair, or two padding rows; workgroup 0 the three pose rows), forms their G entries
 /// from the P rows it reads, re-forms the three pose rows of G it needs for H G (their P rows stay in L2), and writes G and S
 /// without G ever being read back.  Also copies Y^T into row n of G.  Threads run over landmark column pairs.
-/// grid (2 + NP/2, B), 256 threads.
+/// P is binary64 in both modes and the products are formed in binary64; G and S are rounded to T on the way out (in fp32 mode
+/// that is the one rounding of G).  Only the lower triangle of S is consumed downstream, but whole rows are written: the
+/// row is in flight anyway.  grid (2 + NP/2, B), 256 threads.
 template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevView d, LargeView<T> lv, const int *skipped)
 {
         const int b = blockIdx.y;
@@ -277,11 +278,11 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
         const int n = d.n[b], NP = lv.NP;
         const int na = large_blocks(n) * LB;
         const int nl = (n - 3) / 2;
-        const T *P = lv.P + (size_t)b * NP * NP;
+        const double *P = lv.P + (size_t)b * NP * NP;
         T *G = lv.G + (size_t)b * NP * NP;
         T *S = lv.S + (size_t)b * NP * NP;
         const double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
-        const T rm = (T)(double)KR;
+        const double rm = (double)KR;
         const int tid = threadIdx.x;
         const bool pose = (blockIdx.x == 0);
         const int r0 = pose ? 0 : 3 + 2 * ((int)blockIdx.x - 1); // first row of this workgroup
@@ -303,24 +304,25 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                 return;
         }
         // G(a, :) for one row a of P: columns 0..2 copy P, landmark column pair j mixes (t0, t1, t2, ta, tb) with H_j
-        const T *p0 = P, *p1 = P + NP, *p2 = P + 2 * (size_t)NP;
-        const T t00 = p0[0], t01 = p0[1], t02 = p0[2], t10 = p1[0], t11 = p1[1], t12 = p1[2], t20 = p2[0], t21 = p2[1], t22 = p2[2];
-        const T *pa = P + (size_t)r0 * NP, *pb = pa + NP; // landmark rows (unused by the pose workgroup)
-        T ta0 = 0, ta1 = 0, ta2 = 0, tb0 = 0, tb1 = 0, tb2 = 0, ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0;
+        const double *p0 = P, *p1 = P + NP, *p2 = P + 2 * (size_t)NP;
+        const double t00 = p0[0], t01 = p0[1], t02 = p0[2], t10 = p1[0], t11 = p1[1], t12 = p1[2], t20 = p2[0], t21 = p2[1], t22 = p2[2];
+        const double *pa = P + (size_t)r0 * NP, *pb = pa + NP; // landmark rows (unused by the pose workgroup)
+        double ta0 = 0, ta1 = 0, ta2 = 0, tb0 = 0, tb1 = 0, tb2 = 0, ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0;
         if (!pose)
         {
                 ta0 = pa[0], ta1 = pa[1], ta2 = pa[2];
                 tb0 = pb[0], tb1 = pb[1], tb2 = pb[2];
                 const double *hr = Hc + 4 * ((r0 - 3) >> 1);
-                ha0 = (T)hr[0], ha1 = (T)hr[1], hb0 = (T)hr[2], hb1 = (T)hr[3]; // H rows r0 (range) and r0+1 (bearing)
+                ha0 = hr[0], ha1 = hr[1], hb0 = hr[2], hb1 = hr[3]; // H rows r0 (range) and r0+1 (bearing)
         }
-        auto grow = [](T h00, T h01, T h10, T h11, T t0, T t1, T t2, T ta, T tb, T &ge, T &go) {
+        auto grow = [](double h00, double h01, double h10, double h11, double t0, double t1, double t2, double ta, double tb, double &ge,
+                       double &go) {
                 ge = h00 * t0 + h01 * t1 - h00 * ta - h01 * tb;
                 go = h10 * t0 + h11 * t1 - t2 - h10 * ta - h11 * tb;
         };
         // S(r, c) = (H G)(r, c) for landmark row r = r0 (+1): ha g0 + hb g1 [- g2] - ha ga - hb gb
-        auto srow = [](T ha, T hb, bool odd, T g0, T g1, T g2, T ga, T gb) -> T {
-                T v = ha * g0 + hb * g1;
+        auto srow = [](double ha, double hb, bool odd, double g0, double g1, double g2, double ga, double gb) -> double {
+                double v = ha * g0 + hb * g1;
                 if (odd)
                         v -= g2;
                 return v - ha * ga - hb * gb;
@@ -329,57 +331,57 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
         if (tid < 3)
         {
                 const int c = tid;
-                const T g0 = p0[c], g1 = p1[c], g2 = p2[c];
+                const double g0 = p0[c], g1 = p1[c], g2 = p2[c];
                 if (pose)
                 {
-                        G[c] = g0, G[NP + c] = g1, G[2 * (size_t)NP + c] = g2;
-                        S[c] = g0 + (c == 0 ? rm : (T)0);
-                        S[NP + c] = g1 + (c == 1 ? rm : (T)0);
-                        S[2 * (size_t)NP + c] = g2 + (c == 2 ? rm : (T)0);
+                        G[c] = (T)g0, G[NP + c] = (T)g1, G[2 * (size_t)NP + c] = (T)g2;
+                        S[c] = (T)(g0 + (c == 0 ? rm : 0.0));
+                        S[NP + c] = (T)(g1 + (c == 1 ? rm : 0.0));
+                        S[2 * (size_t)NP + c] = (T)(g2 + (c == 2 ? rm : 0.0));
                 }
                 else
                 {
-                        const T ga = pa[c], gb = pb[c];
-                        G[(size_t)r0 * NP + c] = ga;
-                        G[(size_t)(r0 + 1) * NP + c] = gb;
-                        S[(size_t)r0 * NP + c] = srow(ha0, ha1, false, g0, g1, g2, ga, gb);
-                        S[(size_t)(r0 + 1) * NP + c] = srow(hb0, hb1, true, g0, g1, g2, ga, gb);
+                        const double ga = pa[c], gb = pb[c];
+                        G[(size_t)r0 * NP + c] = (T)ga;
+                        G[(size_t)(r0 + 1) * NP + c] = (T)gb;
+                        S[(size_t)r0 * NP + c] = (T)srow(ha0, ha1, false, g0, g1, g2, ga, gb);
+                        S[(size_t)(r0 + 1) * NP + c] = (T)srow(hb0, hb1, true, g0, g1, g2, ga, gb);
                 }
         }
         // ---- landmark column pairs
         for (int j = tid; j < nl; j += 256)
         {
                 const int ce = 3 + 2 * j, co = ce + 1;
-                const T h00 = (T)Hc[4 * j], h01 = (T)Hc[4 * j + 1], h10 = (T)Hc[4 * j + 2], h11 = (T)Hc[4 * j + 3];
-                T g0e, g0o, g1e, g1o, g2e, g2o;
+                const double h00 = Hc[4 * j], h01 = Hc[4 * j + 1], h10 = Hc[4 * j + 2], h11 = Hc[4 * j + 3];
+                double g0e, g0o, g1e, g1o, g2e, g2o;
                 grow(h00, h01, h10, h11, t00, t01, t02, p0[ce], p0[co], g0e, g0o);
                 grow(h00, h01, h10, h11, t10, t11, t12, p1[ce], p1[co], g1e, g1o);
                 grow(h00, h01, h10, h11, t20, t21, t22, p2[ce], p2[co], g2e, g2o);
                 if (pose)
                 {
-                        G[ce] = g0e, G[co] = g0o;
-                        G[NP + ce] = g1e, G[NP + co] = g1o;
-                        G[2 * (size_t)NP + ce] = g2e, G[2 * (size_t)NP + co] = g2o;
-                        S[ce] = g0e, S[co] = g0o;
-                        S[NP + ce] = g1e, S[NP + co] = g1o;
-                        S[2 * (size_t)NP + ce] = g2e, S[2 * (size_t)NP + co] = g2o;
+                        G[ce] = (T)g0e, G[co] = (T)g0o;
+                        G[NP + ce] = (T)g1e, G[NP + co] = (T)g1o;
+                        G[2 * (size_t)NP + ce] = (T)g2e, G[2 * (size_t)NP + co] = (T)g2o;
+                        S[ce] = (T)g0e, S[co] = (T)g0o;
+                        S[NP + ce] = (T)g1e, S[NP + co] = (T)g1o;
+                        S[2 * (size_t)NP + ce] = (T)g2e, S[2 * (size_t)NP + co] = (T)g2o;
                 }
                 else
                 {
-                        T gae, gao, gbe, gbo;
+                        double gae, gao, gbe, gbo;
                         grow(h00, h01, h10, h11, ta0, ta1, ta2, pa[ce], pa[co], gae, gao);
                         grow(h00, h01, h10, h11, tb0, tb1, tb2, pb[ce], pb[co], gbe, gbo);
                         T *ga = G + (size_t)r0 * NP, *gb = ga + NP, *sa = S + (size_t)r0 * NP, *sb = sa + NP;
-                        ga[ce] = gae, ga[co] = gao;
-                        gb[ce] = gbe, gb[co] = gbo;
-                        T se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
-                        T ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
+                        ga[ce] = (T)gae, ga[co] = (T)gao;
+                        gb[ce] = (T)gbe, gb[co] = (T)gbo;
+                        double se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
+                        double ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
                         if (ce == r0)
                                 se += rm; // R on the diagonal
                         if (co == r0 + 1)
                                 uo += rm;
-                        sa[ce] = se, sa[co] = so;
-                        sb[ce] = ue, sb[co] = uo;
+                        sa[ce] = (T)se, sa[co] = (T)so;
+                        sb[ce] = (T)ue, sb[co] = (T)uo;
                 }
         }
         // ---- zero padding columns n .. na-1
@@ -428,7 +430,7 @@ template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevV
         if (k >= large_blocks(n))
                 return;
         T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
-        T *Li = lv.Linv + (size_t)b * LB * LB;
+        T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
         const int lane = threadIdx.x;
         typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
         constexpr int VW = 16 / sizeof(T);
@@ -502,26 +504,28 @@ template <typename T> __device__ __forceinline__ T *stacked_row(const LargeView<
 /// the block row of L is staged once for both, 128 MFMAs per wave between barriers); the two halves are addressed
 /// independently because the pair may straddle the S / G boundary.  4 waves, wave w = rows 32w..32w+31 of the tile as
 /// 2x4 MFMA 16x16 tiles.  The next K slab is fetched into registers while the current one is multiplied.
-/// grid (ceil((2 nb - k0 - 1) / 2), 1, B), 256 threads.
-template <typename T> __global__ __launch_bounds__(256) void large_update_panel(DevView d, LargeView<T> lv, int k0, const int *skipped)
+/// grid (ceil((2 nb - k0 - 1) / 2), 1, B) -- or (ceil((nb - k0 - 1) / 2), 1, B) with s_only: the blocks of S alone --, 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void large_update_panel(DevView d, LargeView<T> lv, int k0, int s_only, const int *skipped)
 {
         typedef Mfma<T> MM;
         constexpr int KC = (sizeof(T) == 4) ? 64 : 32; // columns staged per round = 256 bytes of a row
-        constexpr int LD = KC + 4;
+        constexpr int LD = KC + (sizeof(T) == 4 ? 8 : 4); // fp32: 18 sixteen-byte slots per row -> conflict-free ds_read_b128 operand reads
         typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
         constexpr int VW = 16 / sizeof(T);
         static_assert(KC / VW == 16, "16 lanes per staged row");
-        __shared__ T As[2 * LB][LD];
-        __shared__ T Bs[LB][LD];
+        __shared__ __attribute__((aligned(16))) T As[2 * LB][LD];
+        __shared__ __attribute__((aligned(16))) T Bs[LB][LD];
         const int b = blockIdx.z;
         if (skipped[b])
                 return;
         const int n = d.n[b], NP = lv.NP;
         const int nb = large_blocks(n), na = nb * LB;
         const int rt0 = k0 + 1 + 2 * blockIdx.x; // first virtual 64-row block: S rows below the diagonal block, then all of G
-        if (k0 >= nb || rt0 >= 2 * nb)
+        const int vlim = s_only ? nb : 2 * nb;    // s_only: the rows of G are solved by large_trsm_resident instead
+        if (k0 >= nb || rt0 >= vlim)
                 return;
-        const bool two = rt0 + 1 < 2 * nb; // the last workgroup may have a single block
+        const bool two = rt0 + 1 < vlim; // the last workgroup may have a single block
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         const int half = wave >> 1;            // which 64-row block this wave's rows belong to
         const int rt = rt0 + half;             // its virtual block index
@@ -539,6 +543,30 @@ template <typename T> __global__ __launch_bounds__(256) void large_update_panel(
         clear();
         // acc += As(rows of this wave) * Bsrc(rows vb .. vb+63)^T over one staged slab
         auto multiply = [&](const T(*Bsrc)[LD], int vb) {
+                if constexpr (sizeof(T) == 4)
+                {
+                        // one 16-byte LDS read per operand row feeds four MFMA steps: lane (li, lg) holds k = 16 c + 4 lg + r for
+                        // step r -- a permuted walk over the contraction index, the same for both operands
+#pragma unroll
+                        for (int c = 0; c < KC / 16; ++c)
+                        {
+                                f4 av[2], bv[4];
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+                                        av[u] = *reinterpret_cast<const f4 *>(&As[wr + 16 * u + li][16 * c + 4 * lg]);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                        bv[v] = *reinterpret_cast<const f4 *>(&Bsrc[vb + 16 * v + li][16 * c + 4 * lg]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                                for (int v = 0; v < 4; ++v)
+                                                        acc[u][v] = MM::mma(av[u][r], bv[v][r], acc[u][v]);
+                        }
+                        return;
+                }
 #pragma unroll
                 for (int s = 0; s < KC / 4; ++s)
                 {
@@ -608,7 +636,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_update_panel(
                                 cr[u][v][r] = Ctile[(size_t)(16 * u + MM::row(lane, r)) * NP + 16 * v + li] - acc[u][v][r];
         clear();
         // ---- X = C Linv^T, K = 64 in slabs of KC: stage C (from registers) and Linv (row c of Linv = column c of the product)
-        const T *Li = lv.Linv + (size_t)b * LB * LB;
+        const T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k0) * LB * LB;
         auto stage_regs = [&](const typename MM::acc_t(&src)[2][4], int kh) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -678,6 +706,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_update_panel(
 template <typename T>
 __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, int nfilters, const int *skipped)
 {
+        static_assert(sizeof(T) == 8, "binary32 products go through large_syrk_f32p64");
         typedef Mfma<T> MM;
         constexpr int TB = 128;
         constexpr int KC = (sizeof(T) == 4) ? 32 : 16;
@@ -809,25 +838,177 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
                                 // mirror into the upper triangle.  fp32: a lane's four registers are four consecutive rows of
                                 // the tile = 16 contiguous bytes of the mirrored row: one 16-byte read-modify-write
                                 const int row0 = rt * TB + wr + 16 * u + MM::row(lane, 0);
-                                T *m = P + (size_t)col * NP + row0;
-                                if (sizeof(T) == 4 && row0 + 3 < n)
-                                {
-                                        typedef T vec4_t __attribute__((ext_vector_type(4)));
-                                        vec4_t x = *reinterpret_cast<vec4_t *>(m);
+                                (void)row0;
 #pragma unroll
-                                        for (int r = 0; r < 4; ++r)
-                                                x[r] -= acc[u][v][r];
-                                        *reinterpret_cast<vec4_t *>(m) = x;
+                                for (int r = 0; r < 4; ++r)
+                                {
+                                        const int row = rt * TB + wr + 16 * u + MM::row(lane, r);
+                                        if (row < n)
+                                                P[(size_t)col * NP + row] -= acc[u][v][r];
+                                }
+                        }
+                }
+}
+
+/// P -= V V^T, round-2 form for binary32 products: P is stored in binary64 (the update V V^T is small against P in steady state,
+/// so rounding the UPDATE to binary32 and accumulating it into an fp64 P costs eps32 |dP| per callback instead of eps32 |P|:
+/// tools/fp32_drift_model.py), V in binary32.  Same 128x128 tiling as large_syrk (4 waves x 4x4 MFMA 16x16x4 tiles, lower tiles
+/// only, a filter's tiles on one XCD); differences:
+///   * operand fragments come out of LDS as ONE 16-byte read per four MFMAs: lane (i = l & 15, g = l >> 4) reads the four
+///     consecutive floats k = 16 c + 4 g .. + 3 of its row and uses component r in MFMA step r, i.e. the contraction index is
+///     visited in a permuted order, the same for both operands (row stride KC + 8 floats: conflict-free for ds_read_b128);
+///   * the K loop stops at the filter's size n (columns n .. of V are zero), not at the padded size;
+///   * the lower tile is read-modify-written in fp64 and its NEW value is stored, transposed, into the upper triangle (32 bytes per
+///     lane and register quadruple) -- no read of the upper triangle, and P stays exactly symmetric.
+/// grid (8 * lower tiles * ceil(B/8)), 256 threads.
+template <int KC>
+__global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
+{
+        constexpr int TB = 128;
+        constexpr int LD = KC + 8;
+        __shared__ __attribute__((aligned(16))) float As[TB * LD];
+        __shared__ __attribute__((aligned(16))) float Bs[TB * LD];
+        const int ntile = (lv.NP + TB - 1) / TB, nlow = ntile * (ntile + 1) / 2;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nlow) * 8 + (blockIdx.x & 7);
+        if (b >= nfilters || skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int na = large_blocks(n) * LB;
+        const int tl = slot % nlow;
+        int rt = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while ((rt + 1) * (rt + 2) / 2 <= tl)
+                ++rt;
+        while (rt * (rt + 1) / 2 > tl)
+                --rt;
+        const int jt = tl - rt * (rt + 1) / 2;
+        if (rt * TB >= n)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+        const float *G = lv.G + (size_t)b * NP * NP;
+        double *P = lv.P + (size_t)b * NP * NP;
+        // staging: KC / 4 lanes cover one row segment of a slab with 16-byte loads; 256 * 4 / KC rows per pass
+        constexpr int LPR = KC / 4, RPP = 256 / LPR, NPASS = TB / RPP;
+        const int lrow = tid / LPR, lc0 = (tid % LPR) * 4;
+        const float *Ap[NPASS], *Bp[NPASS];
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+        {
+                Ap[q] = G + (size_t)min(rt * TB + lrow + RPP * q, na - 1) * NP + lc0;
+                Bp[q] = G + (size_t)min(jt * TB + lrow + RPP * q, na - 1) * NP + lc0;
+        }
+        f4 acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        acc[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
+        f4 ta[NPASS], tb[NPASS];
+        auto fetch = [&](int kc) {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q)
+                {
+                        ta[q] = *reinterpret_cast<const f4 *>(Ap[q] + kc);
+                        tb[q] = *reinterpret_cast<const f4 *>(Bp[q] + kc);
+                }
+        };
+        const bool idle = (rt == jt && wc > wr); // upper quadrant of a diagonal tile: the mirror image of its lower one
+        const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
+        const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
+        const bool full = (nu == 4 && nv == 4);
+        const int kend = min(na, (n + KC - 1) / KC * KC); // columns n .. na-1 of V are zero (G = P H^T is zero there and L is the identity)
+        const int a_off = (wr + li) * LD + 4 * lg, b_off = (wc + li) * LD + 4 * lg;
+        fetch(0);
+        for (int kc = 0; kc < kend; kc += KC)
+        {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q)
+                {
+                        *reinterpret_cast<f4 *>(&As[(lrow + RPP * q) * LD + lc0]) = ta[q];
+                        *reinterpret_cast<f4 *>(&Bs[(lrow + RPP * q) * LD + lc0]) = tb[q];
+                }
+                __syncthreads();
+                if (kc + KC < kend)
+                        fetch(kc + KC);
+                if (full)
+                {
+#pragma unroll
+                        for (int c = 0; c < KC / 16; ++c)
+                        {
+                                f4 av[4], bv[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                {
+                                        av[u] = *reinterpret_cast<const f4 *>(&As[a_off + 16 * u * LD + 16 * c]);
+                                        bv[u] = *reinterpret_cast<const f4 *>(&Bs[b_off + 16 * u * LD + 16 * c]);
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                                for (int v = 0; v < 4; ++v)
+                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], bv[v][r], acc[u][v], 0, 0, 0);
+                        }
+                }
+                else
+                {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                                if (u < nu)
+#pragma unroll
+                                        for (int v = 0; v < 4; ++v)
+                                                if (v < nv)
+#pragma unroll
+                                                        for (int c = 0; c < KC / 16; ++c)
+                                                        {
+                                                                const f4 a4 = *reinterpret_cast<const f4 *>(&As[a_off + 16 * u * LD + 16 * c]);
+                                                                const f4 b4 = *reinterpret_cast<const f4 *>(&Bs[b_off + 16 * v * LD + 16 * c]);
+#pragma unroll
+                                                                for (int r = 0; r < 4; ++r)
+                                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], b4[r], acc[u][v], 0, 0, 0);
+                                                        }
+                }
+                __syncthreads();
+        }
+        if (idle)
+                return;
+        const bool mirror = (jt < rt || wc < wr);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                {
+                        const int col = jt * TB + wc + 16 * v + li;
+                        const int row0 = rt * TB + wr + 16 * u + 4 * lg;
+                        double nv4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                nv4[r] = 0.0;
+                                if (row0 + r < n && col < n) // keep P's padding clean (row n of G is Y^T, not V)
+                                {
+                                        double *pp = P + (size_t)(row0 + r) * NP + col;
+                                        nv4[r] = *pp - (double)acc[u][v][r];
+                                        *pp = nv4[r];
+                                }
+                        }
+                        if (mirror && col < n)
+                        {
+                                double *m = P + (size_t)col * NP + row0; // four consecutive rows of the tile = 32 contiguous bytes of the mirrored row
+                                if (row0 + 3 < n)
+                                {
+                                        typedef double d2 __attribute__((ext_vector_type(2)));
+                                        *reinterpret_cast<d2 *>(m) = (d2){nv4[0], nv4[1]};
+                                        *reinterpret_cast<d2 *>(m + 2) = (d2){nv4[2], nv4[3]};
                                 }
                                 else
                                 {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
-                                        {
-                                                const int row = rt * TB + wr + 16 * u + MM::row(lane, r);
-                                                if (row < n)
-                                                        P[(size_t)col * NP + row] -= acc[u][v][r];
-                                        }
+                                                if (row0 + r < n)
+                                                        m[r] = nv4[r];
                                 }
                         }
                 }
@@ -868,3 +1049,5 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
         }
 }
 } // namespace aslam
+
+#include "ekf_large_trsm.h"

@@ -1,0 +1,307 @@
+// ekf_large_trsm.h -- V = G L^-T for the large-state EKF in binary32 (K = P H^T S^-1 = V L^-1, ekf.cpp:301), with the
+// solved block columns kept in REGISTERS.
+//
+// Once S = L L^T is factored (blocked Cholesky, 64-wide block columns, inverses of the diagonal blocks in lv.Linv) every row of
+// G is independent:  V(i, k) = ( G(i, k) - sum_{j<k} V(i, j) L(k, j)^T ) Linv_k^T.   A left-looking sweep that keeps V in HBM
+// re-reads the solved columns once per block column (38 MB per filter and callback at n = 1027, the largest item of the
+// fabric traffic of round 1).  Here a wave owns 16 rows of G and holds their whole solved row strip -- 17 block columns x 64
+// = 1088 columns -- as 68 MFMA accumulator tiles (272 registers): G is read once, V is written once, and only L streams by.
+//
+// The strip is held TRANSPOSED: tile q of a wave is W = V^T restricted to rows [16 q, 16 q + 16) x the wave's 16 columns,
+// in the 16x16x4 accumulator layout  reg r of lane l = W[16 q + 4 (l >> 4) + r][l & 15].  In that layout register r of a
+// finished tile IS the B operand (k = l >> 4, n = l & 15) of a later product that contracts over W's row index, for the four
+// rows k' = 4 (l >> 4) + r; the matching A operand (i = l & 15, k = l >> 4) is L[i][16 q + 4 (l >> 4) + r]: four consecutive
+// floats of a row of L, i.e. ONE 16-byte LDS read feeds four MFMAs, and no accumulator is ever moved, transposed or
+// re-read.  (The contraction index is visited in a permuted order; both operands use the same permutation.)
+//
+// The 64x64 blocks of L -- L(k, 0) .. L(k, k-1), then Linv_k -- are shared by the four waves of a workgroup and stream
+// through two LDS buffers (register prefetch one block ahead, one barrier per block).  Register indices must be static: the
+// sweep runs as two run-time loops (block column k, history block j) around a 17-way wave-uniform switch on j whose cases are
+// the 64 MFMAs against strip tiles 4 j .. 4 j + 3 -- 12 KB of code that stays in the instruction cache (the first version
+// unrolled all 153 blocks: 150 KB of straight-line code, every line an instruction-cache miss, 55 % of the MFMA rate).
+// One workgroup per CU (the strip needs most of the register file), 64 MFMAs per wave between barriers.
+// n^3 flops like any triangular solve with n right-hand sides, plus the 64-deep Linv products.
+#pragma once
+
+namespace aslam
+{
+constexpr int TRSM_LDT = LB + 8; // LDS row stride in floats: 18 sixteen-byte slots -> conflict-free ds_read_b128 operand reads
+
+/// global -> registers: this thread's share (4 x 16 bytes) of a 64x64 block with row stride `ld`
+__device__ __forceinline__ void trsm_fetch(f4 (&pf)[4], const float *blk, int ld, int tid)
+{
+        const int r0 = tid >> 4, c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+                pf[q] = *reinterpret_cast<const f4 *>(blk + (size_t)(r0 + 16 * q) * ld + c4);
+}
+
+/// registers -> LDS buffer [64][TRSM_LDT]
+__device__ __forceinline__ void trsm_stash(float *buf, const f4 (&pf)[4], int tid)
+{
+        const int r0 = tid >> 4, c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f4 *>(buf + (r0 + 16 * q) * TRSM_LDT + c4) = pf[q];
+}
+
+// ---- the strip lives in AGPRs a0 .. a255 that the compiler never sees: every MFMA of this kernel is inline assembly with
+// VGPR ("v") accumulators and A operands, so no value of the compiler's is ever placed in an AGPR; the strip tiles are named
+// by number (tile T = registers a[4T .. 4T+3]) as B operands and written with v_accvgpr_write.  (Left to the compiler -- a
+// 64-tile array indexed statically inside the switch cases -- the 256-value phi web around the two loops ended in 1 800
+// v_accvgpr copies and 520 spilled registers.)  hipcc inserts no wait states inside or around inline assembly: the blocks end
+// in the s_nop a following VALU / store read of an MFMA result needs (16x16x4 f32: 8 passes).
+
+/// c[t] += A-fragments a[t] (one 16-byte LDS read each: four k values) x strip tile T, t = 0 .. 3: 16 MFMAs
+template <int T> __device__ __forceinline__ void trsm_mfma_tile(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3)
+{
+        static_assert(T >= 0 && T < 64, "strip tile");
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c20, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %8, a%c20, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %12, a%c20, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %16, a%c20, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %5, a%c21, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %9, a%c21, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %13, a%c21, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %17, a%c21, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %6, a%c22, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c22, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %14, a%c22, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %18, a%c22, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %7, a%c23, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c23, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %15, a%c23, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %19, a%c23, %3"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]),
+                       "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]), "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2),
+                       "n"(4 * T + 3));
+}
+
+/// c[t] += L(k, J)(rows 16 t ..) * W(tiles 4 J .. 4 J + 3): the 64 MFMAs of one history block
+template <int J> __device__ __forceinline__ void trsm_history(f4 (&c)[4], const float *buf, int a_off)
+{
+        f4 a[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        a[q][t] = *reinterpret_cast<const f4 *>(buf + a_off + 16 * t * TRSM_LDT + 16 * q);
+        trsm_mfma_tile<4 * J + 0>(c[0], c[1], c[2], c[3], a[0][0], a[0][1], a[0][2], a[0][3]);
+        trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a[1][0], a[1][1], a[1][2], a[1][3]);
+        trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a[2][0], a[2][1], a[2][2], a[2][3]);
+        trsm_mfma_tile<4 * J + 3>(c[0], c[1], c[2], c[3], a[3][0], a[3][1], a[3][2], a[3][3]);
+}
+
+/// x[tp] += Linv(tile tp, tile t) * C(tile t) for tp = t .. 3 (Linv is lower triangular in tiles): B operand = c in VGPRs
+template <int NTP>
+__device__ __forceinline__ void trsm_mfma_x(f4 &x0, f4 &x1, f4 &x2, f4 &x3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, const f4 &c)
+{
+        // NTP = number of target tiles (4 - t); targets are the LAST NTP of x0..x3, fragments a0..a(NTP-1) belong to them in order
+        if constexpr (NTP == 4)
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, %20, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %20, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %12, %20, %2\n\tv_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %5, %21, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %21, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %13, %21, %2\n\tv_mfma_f32_16x16x4_f32 %3, %17, %21, %3\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %6, %22, %0\n\tv_mfma_f32_16x16x4_f32 %1, %10, %22, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %14, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %18, %22, %3\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %7, %23, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %23, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %15, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %19, %23, %3"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
+                             : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]),
+                               "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]), "v"(c[0]), "v"(c[1]),
+                               "v"(c[2]), "v"(c[3]));
+        else if constexpr (NTP == 3)
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %3, %15, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %11, %15, %2\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %4, %16, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %12, %16, %2\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %5, %17, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %17, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %13, %17, %2\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %6, %18, %0\n\tv_mfma_f32_16x16x4_f32 %1, %10, %18, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %14, %18, %2"
+                             : "+v"(x1), "+v"(x2), "+v"(x3)
+                             : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]),
+                               "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+        else if constexpr (NTP == 2)
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\tv_mfma_f32_16x16x4_f32 %1, %6, %10, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %11, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %12, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %13, %1"
+                             : "+v"(x2), "+v"(x3)
+                             : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(c[0]),
+                               "v"(c[1]), "v"(c[2]), "v"(c[3]));
+        else
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %5, %0\n\tv_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\tv_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
+                             : "+v"(x3)
+                             : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+}
+
+/// X = Linv C for one block column (four accumulators in flight), V tile stores; returns X in x[]
+__device__ __forceinline__ void trsm_solve_block(f4 (&x)[4], const f4 (&c)[4], const float *buf, int a_off, float *vout)
+{
+        f4 a[4][4]; // a[t][i]: fragment of Linv tile (row tile t + i, column tile t)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4 - t; ++i)
+                        a[t][i] = *reinterpret_cast<const f4 *>(buf + a_off + 16 * (t + i) * TRSM_LDT + 16 * t);
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+                x[tp] = (f4){0.f, 0.f, 0.f, 0.f};
+        trsm_mfma_x<4>(x[0], x[1], x[2], x[3], a[0][0], a[0][1], a[0][2], a[0][3], c[0]);
+        trsm_mfma_x<3>(x[0], x[1], x[2], x[3], a[1][0], a[1][1], a[1][2], a[1][2], c[1]);
+        trsm_mfma_x<2>(x[0], x[1], x[2], x[3], a[2][0], a[2][1], a[2][1], a[2][1], c[2]);
+        trsm_mfma_x<1>(x[0], x[1], x[2], x[3], a[3][0], a[3][0], a[3][0], a[3][0], c[3]);
+        asm volatile("s_nop 15" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); // MFMA result -> store data
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<f4 *>(vout + 16 * t) = x[t];
+}
+
+/// strip tiles 4 K .. 4 K + 3 <- x
+template <int K> __device__ __forceinline__ void trsm_keep(const f4 (&x)[4])
+{
+        asm volatile("v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\tv_accvgpr_write_b32 a%c11, %3\n\t"
+                     "v_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\tv_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7"
+                     :
+                     : "v"(x[0][0]), "v"(x[0][1]), "v"(x[0][2]), "v"(x[0][3]), "v"(x[1][0]), "v"(x[1][1]), "v"(x[1][2]), "v"(x[1][3]),
+                       "n"(16 * K), "n"(16 * K + 1), "n"(16 * K + 2), "n"(16 * K + 3), "n"(16 * K + 4), "n"(16 * K + 5), "n"(16 * K + 6),
+                       "n"(16 * K + 7));
+        asm volatile("v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\tv_accvgpr_write_b32 a%c11, %3\n\t"
+                     "v_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\tv_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7\n\t"
+                     "s_nop 3"
+                     :
+                     : "v"(x[2][0]), "v"(x[2][1]), "v"(x[2][2]), "v"(x[2][3]), "v"(x[3][0]), "v"(x[3][1]), "v"(x[3][2]), "v"(x[3][3]),
+                       "n"(16 * K + 8), "n"(16 * K + 9), "n"(16 * K + 10), "n"(16 * K + 11), "n"(16 * K + 12), "n"(16 * K + 13),
+                       "n"(16 * K + 14), "n"(16 * K + 15));
+}
+
+/// grid (NP / 64, B), 256 threads; wave w of workgroup x owns rows [64 x + 16 w, +16) of G.  In place: G -> V.
+template <int NBMAX>
+__global__ __launch_bounds__(256, 1) void large_trsm_resident(DevView d, LargeView<float> lv, const int *skipped)
+{
+        static_assert(NBMAX == 17, "the switch below lists 17 block columns");
+        __shared__ __attribute__((aligned(16))) float lds[2][LB * TRSM_LDT];
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        if ((int)blockIdx.x >= nb)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * blockIdx.x + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
+        const float *Sb = lv.S + (size_t)b * NP * NP;
+        const float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
+        // LDS read offset of this lane's A fragments: row 16 t + li, sixteen-byte slot 4 q + lg
+        const int a_off = li * TRSM_LDT + 4 * lg;
+
+        // the strip: a0 .. a255 (tiles 0 .. 63; the last block column is never a history block).  Naming them as clobbers here is what
+        // makes the kernel descriptor allocate them; nothing of the compiler's lives in an AGPR (all MFMAs are inline assembly on VGPRs)
+        asm volatile("" ::: "a0", "a255");
+        f4 pf[4];
+        // block sequence: for k: L(k,0) .. L(k,k-1), Linv_k.  Block 0 is Linv_0.
+        trsm_fetch(pf, Linv, LB, tid);
+        trsm_stash(lds[0], pf, tid);
+        __syncthreads();
+        int cur = 0;
+#pragma unroll 1
+        for (int k = 0; k < nb; ++k)
+        {
+                f4 c[4], g0[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                {
+                        c[t] = (f4){0.f, 0.f, 0.f, 0.f};
+                        g0[t] = *reinterpret_cast<const f4 *>(Grow + LB * k + 16 * t); // G[row][64 k + 16 t + 4 lg .. +3]
+                }
+#pragma unroll 1
+                for (int jb = 0; jb < k; ++jb)
+                {
+                        // prefetch the next block: L(k, jb+1), or Linv_k after the last history block
+                        if (jb + 1 < k)
+                                trsm_fetch(pf, Sb + (size_t)(LB * k) * NP + LB * (jb + 1), NP, tid);
+                        else
+                                trsm_fetch(pf, Linv + (size_t)k * LB * LB, LB, tid);
+                        const float *buf = lds[cur];
+                        switch (jb)
+                        {
+#define ASLAM_TRSM_CASE(J)                                                                                             \
+        case J:                                                                                                        \
+                trsm_history<J>(c, buf, a_off);                                                                     \
+                break;
+                                ASLAM_TRSM_CASE(0)
+                                ASLAM_TRSM_CASE(1)
+                                ASLAM_TRSM_CASE(2)
+                                ASLAM_TRSM_CASE(3)
+                                ASLAM_TRSM_CASE(4)
+                                ASLAM_TRSM_CASE(5)
+                                ASLAM_TRSM_CASE(6)
+                                ASLAM_TRSM_CASE(7)
+                                ASLAM_TRSM_CASE(8)
+                                ASLAM_TRSM_CASE(9)
+                                ASLAM_TRSM_CASE(10)
+                                ASLAM_TRSM_CASE(11)
+                                ASLAM_TRSM_CASE(12)
+                                ASLAM_TRSM_CASE(13)
+                                ASLAM_TRSM_CASE(14)
+                        default:
+                                trsm_history<15>(c, buf, a_off);
+                                break;
+#undef ASLAM_TRSM_CASE
+                        }
+                        trsm_stash(lds[cur ^ 1], pf, tid);
+                        __syncthreads();
+                        cur ^= 1;
+                }
+                // C = G - history
+                asm volatile("s_nop 15" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); // MFMA result -> VALU read
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        c[t] = g0[t] - c[t];
+                // prefetch the first history block of the next block column (if there is one)
+                const bool more = (k + 1 < nb);
+                if (more)
+                        trsm_fetch(pf, Sb + (size_t)(LB * (k + 1)) * NP, NP, tid);
+                // X = Linv_k C, stored to V, and kept as strip tiles 4 k .. 4 k + 3 (static register names: a switch on the block column)
+                {
+                        f4 x[4];
+                        trsm_solve_block(x, c, lds[cur], a_off, Grow + LB * k);
+                        switch (k)
+                        {
+#define ASLAM_TRSM_KEEP(K)                                                                                             \
+        case K:                                                                                                        \
+                trsm_keep<K>(x);                                                                                       \
+                break;
+                                ASLAM_TRSM_KEEP(0)
+                                ASLAM_TRSM_KEEP(1)
+                                ASLAM_TRSM_KEEP(2)
+                                ASLAM_TRSM_KEEP(3)
+                                ASLAM_TRSM_KEEP(4)
+                                ASLAM_TRSM_KEEP(5)
+                                ASLAM_TRSM_KEEP(6)
+                                ASLAM_TRSM_KEEP(7)
+                                ASLAM_TRSM_KEEP(8)
+                                ASLAM_TRSM_KEEP(9)
+                                ASLAM_TRSM_KEEP(10)
+                                ASLAM_TRSM_KEEP(11)
+                                ASLAM_TRSM_KEEP(12)
+                                ASLAM_TRSM_KEEP(13)
+                                ASLAM_TRSM_KEEP(14)
+                                ASLAM_TRSM_KEEP(15)
+                        default:
+                                break; // the last block column is never a history block
+#undef ASLAM_TRSM_KEEP
+                        }
+                }
+                if (more)
+                {
+                        trsm_stash(lds[cur ^ 1], pf, tid);
+                        __syncthreads();
+                        cur ^= 1;
+                }
+        }
+}
+} // namespace aslam

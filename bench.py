@@ -150,6 +150,26 @@ def cpu_baseline_all_cores(kind, L, seed, sample):
                       f"and overlap for {max(overlap, 0.0):.1f} s"}
 
 
+def sub_records(seed):
+    """configs[1] (ekf64) and configs[2] (ukf64) on the same clock as the default line, as sub-records with fixed shapes
+    (whatever --steps/--warmup say; the UKF stays within the callbacks the reference UKF survives).  Each runs in a fresh
+    process of its own, like a stand-alone `bench.py --workload ...`: measured in-process after the 5 GB configs[3] context the
+    UKF launch took twice as long (profiles/r02_experiments.md)."""
+    subs = {}
+    for sw, sC, sK, sW in (("ekf64", 500, 4, 1), ("ukf64", 200, 10, 2)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", sw, "--chunk", str(sC), "--steps", str(sK), "--warmup", str(sW),
+               "--seed", str(seed), "--cpu-sample", "0", "--no-sub"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+        if r.returncode != 0:
+            raise SystemExit(f"bench sub-record {sw} failed:\n{r.stderr[-2000:]}")
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        subs[sw] = {"value": line["value"], "unit": line["unit"], "dtype": line["dtype"], "workload": line["config"]["workload"],
+                    "trajectories_per_gpu": line["config"]["trajectories_per_gpu"], "callbacks_per_step": line["config"]["callbacks_per_step"],
+                    "steps": line["steps"], "warmup": line["warmup"], "ms_per_step": line["ms_per_step"], "kernel": line["config"]["kernel"],
+                    "roofline": line["roofline"], "single_trajectory": line.get("single_trajectory")}
+    return subs
+
+
 def make_core(workload, B, tr, local):
     from awesomeslam_amd import trace as tg
     from awesomeslam_amd.core import Core, F32, F64
@@ -301,6 +321,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
+    subs = None
+    if args.gpus == 1 and args.workload == "ekf512" and args.scaling == "weak" and not args.no_sub:
+        subs = sub_records(args.seed)  # fresh processes, before this one touches the GPU
+
     import torch
     from awesomeslam_amd import dist as adist
     from awesomeslam_amd import trace as tg
@@ -348,15 +372,8 @@ def main():
         }
         if world == 1:
             out["single_trajectory"] = single_trajectory_latency(wl, args.seed, min(C, 200), local, dev)
-            if wl == "ekf512" and args.scaling == "weak" and not args.no_sub:
-                # configs[1] and configs[2] on the same clock, as sub-records (fixed shapes, whatever --steps/--warmup say)
-                out["sub"] = {}
-                for sw, sC, sK, sW in (("ekf64", 500, 4, 1), ("ukf64", 200, 6, 2)):
-                    sel, sks, sinfo, _ = measure(sw, 256, sC, sK, sW, args.seed, 0, 0, 1, local, dev)
-                    skind, sL, sname = WORKLOADS[sw]
-                    out["sub"][sw] = {"value": 256 * sC * sK / sel, "unit": "filter-steps/s", "dtype": "f64", "workload": f"{sw} = {sname}",
-                                      "trajectories_per_gpu": 256, "callbacks_per_step": sC, "steps": sK, "warmup": sW,
-                                      "ms_per_step": sel / sK * 1e3, "kernel": sinfo["name"], "roofline": roofline(sw, 256, sC, sks)}
+            if subs:
+                out["sub"] = subs
             sample = args.cpu_sample
             if sample is None:
                 sample = {"ekf64": 1200, "ukf64": 1000, "ekf8": 20000, "ekf512": 3}[wl]
