@@ -63,6 +63,8 @@ def build(force=False, ukf=True):
     if stale:
         have_ukf = ukf and os.path.exists(os.path.join(_CSRC, "ukf_small.h"))
         subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "all"])
+        # every fresh build is scanned for VGPR spill code in EXEC-empty blocks (a hipcc code-generation bug, tools/check_spill_exec.py)
+        subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "check-spills"])
     return _CORE, _NODE
 
 

@@ -41,8 +41,8 @@ template <int NT> struct UkfLayout
         static constexpr int NP = LY::NP;
         static constexpr int MP = 2 * NP + 16; // >= 2 n + 5 rounded up to 16 for every n <= NP - 1
         static constexpr size_t oXP = (LY::total + 15) & ~(size_t)15; // double[3][MP] propagated sigma-point poses
-        static constexpr size_t oW = oXP + 8 * 3 * MP;                 // double[MP] weights
-        static constexpr size_t oXbar = oW + 8 * MP;                   // double[NP] predicted mean
+        static constexpr size_t oW = oXP + 8 * 3 * MP;                 // double[MP + 1] weights + a spare slot for the threads beyond MP
+        static constexpr size_t oXbar = oW + 8 * (MP + 2);             // double[NP] predicted mean (sW has one spare slot, padded to 16 bytes)
         static constexpr size_t oZpred = oXbar + 8 * NP;               // double[NP]
         // GEMM staging: 2 buffers x (A, B) slabs.  Where it fits it overlays the tile region (the Cholesky factor of
         // P is dead by then, and at NT = 9 there is no room for both); smaller NT get an area of their own.
@@ -284,8 +284,15 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 const double w_0 = (double)(lambda_f / den_f);
                 const double wsp = (double)sqrtf(den_f);
                 const double std_a = sqrt((double)(UKF_STD_A * UKF_STD_A)); // llt of the augmented diagonal, ukf.cpp:276,280
-                for (int i = tid; i < 16 * mt; i += SMALL_WG)
+                {
+                        // One store per thread, none of them masked: threads beyond the padded sigma-point count write a spare slot.
+                        // (A thread-strided loop here leaves EXEC empty at its exit; hipcc has placed VGPR spill stores into exactly
+                        // that exit block, ahead of the instruction that re-activates the lanes -- the stores then write nothing and
+                        // the reloads read uninitialised scratch.  tools/check_spill_exec.py guards every build)
+                        static_assert(UL::MP < SMALL_WG, "one sigma-point weight per thread");
+                        const int i = min(tid, UL::MP);
                         sW[i] = (i < m) ? (i == 0 ? w_0 : w_i) : 0.0;
+                }
 
                 // ---- L = Paug.llt().matrixL(), ukf.cpp:280: lower tiles of P -> LDS -> tile Cholesky
                 {
@@ -307,10 +314,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         }
                 }
                 __syncthreads();
-                // (launch-time tid on purpose: with the opaque per-callback copy the NT = 2 instance of this call -- in effect the
-                // hand-pinned factor_diag_tile_fast inlined into it -- comes out 1e-6 off (bisected with per-phase variants,
-                // profiles/r01_experiments.md); every other phase, and the EKF's cholesky_solve_rows, are bit-for-bit unaffected)
-                cholesky_lookahead<NT>(Lt, Dinv, nt, tid_launch, &sm.status);
+                cholesky_lookahead<NT>(Lt, Dinv, nt, tid, &sm.status);
 
                 ASLAM_STAMP(1);
                 // L(k, c) for c <= k < n from the tile storage (0 above the diagonal)

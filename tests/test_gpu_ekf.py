@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from awesomeslam_amd import trace as tg
-from util import REL_TOL, rel_err, sub_trajectory
+from util import REL_TOL, cov_err, rel_err, sub_trajectory
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,7 @@ def assert_parity(core, b, poses, dims, oracle, po, do, tol=REL_TOL):
         assert np.array_equal(a, c), "wait-list must be bit-exact"
     if core.filter == "ekf":  # A(0,0), A(1,0) come from double sin/cos: device libm vs glibc differ in the last ulp
         assert np.allclose(core.A(b), oracle.A(), rtol=1e-13, atol=1e-16)
-    errs = rel_err(poses, po), rel_err(X, Xo), rel_err(P, Po)
+    errs = rel_err(poses, po), rel_err(X, Xo), cov_err(P, Po)
     assert max(errs) < tol, errs
     return errs
 
@@ -96,7 +96,7 @@ def test_golden(path, built):
     w = core.wait_list(0)
     assert np.array_equal(w[0], z["wait_range"]) and np.array_equal(w[1], z["wait_bearing"]) and np.array_equal(w[2], z["wait_count"])
     assert np.allclose(core.A(0), z["A"], rtol=1e-13, atol=1e-16)
-    assert max(rel_err(poses[0], z["poses"]), rel_err(X, z["X"]), rel_err(P, z["P"])) < REL_TOL
+    assert max(rel_err(poses[0], z["poses"]), rel_err(X, z["X"]), cov_err(P, z["P"])) < REL_TOL
 
 
 @pytest.mark.parametrize("L,T,kw", [(5, 150, dict(seed=31)), (8, 200, dict(seed=32, sensor_every=2)), (13, 120, dict(seed=33, stages=1))])
@@ -115,7 +115,7 @@ def test_per_callback_seam_host_mirror(L, T, kw, built):
     assert np.array_equal(dn, do) and np.array_equal(Z, Zo) and (a00, a10) == o.A()  # host libm on both sides
     for a, c in zip(node.wait_list(), o.wait_list()):
         assert np.array_equal(a, c)
-    assert max(rel_err(pn, po), rel_err(X, Xo), rel_err(node.P(), Po)) < REL_TOL
+    assert max(rel_err(pn, po), rel_err(X, Xo), cov_err(node.P(), Po)) < REL_TOL
 
 
 def test_node_clock_delta_time(built):
@@ -165,7 +165,7 @@ def test_single_slam_on_synthetic_state(n, built):
         Xo, _, Po = o.state()
         assert rel_err(Xg, Xo) < REL_TOL
     _, _, Pg = core.state(1)
-    assert rel_err(Pg, Po) < REL_TOL
+    assert cov_err(Pg, Po) < REL_TOL
     assert core.dim(0) == 3                      # the neighbouring filter of the batch is untouched
     assert np.array_equal(core.state(0)[2], np.eye(3) * float(np.float32(0.001)))
 
@@ -277,4 +277,4 @@ def test_replay_from_trace_file_and_rostopic_dump(built, tmp_path):
     Xo, Zo, Po = o.state()
     X, Z, P = core.state(0)
     assert np.array_equal(d.cpu().numpy()[0], do) and np.array_equal(Z, Zo)
-    assert max(rel_err(p.cpu().numpy()[0], po), rel_err(X, Xo), rel_err(P, Po)) < REL_TOL
+    assert max(rel_err(p.cpu().numpy()[0], po), rel_err(X, Xo), cov_err(P, Po)) < REL_TOL

@@ -1,16 +1,18 @@
 """-m gpu: the multi-workgroup EKF path (state dimensions 144 .. 1087, fp64 and fp32; BASELINE configs[3]/[4]).
 
-fp64: the usual bars (1e-6 relative, bit-exact bookkeeping) against the oracle.  fp32 (configs[3]: "fp32 ... MFMA"):
-the covariance is stored and multiplied in binary32, so 1e-6 against an fp64 reference cannot be promised (SURVEY.md
-section 7 "hard parts"); the bookkeeping is still bit-exact and the measured error is printed and bounded by 1e-4."""
+fp64: the usual bars (1e-6 relative norm-wise AND block-wise, bit-exact bookkeeping) against the oracle.  fp32
+(configs[3]: "fp32 ... MFMA"): G, S, L, V and the MFMA products are binary32, the covariance itself is stored in
+binary64, so a callback costs eps32 |dP| instead of eps32 |P| (tools/fp32_drift_model.py).  The bookkeeping is still
+bit-exact; the covariance bar is F32_TOL, set from the measured errors (printed by every test) with a 2x margin, and
+test_fp32_drift_over_2000_callbacks holds the 1e-6 north-star bar itself over a long horizon."""
 import numpy as np
 import pytest
 
 from awesomeslam_amd import trace as tg
-from util import REL_TOL, rel_err
+from util import REL_TOL, cov_err, rel_err
 
 pytestmark = pytest.mark.gpu
-F32_TOL = 1e-4
+F32_TOL = 4e-6  # measured: <= 1.6e-6 (one slam() on a synthetic P whose update is as large as P itself, n = 1087), <= 1.1e-6 in replays
 
 
 def synth(n, seed):
@@ -45,7 +47,7 @@ def test_single_slam_on_synthetic_state(n, steps, dtype, built):
         o.slam(vx, az, dt)
     Xo, _, Po = o.state()
     Pg = core.state(1)[2]
-    ex, ep = rel_err(Xg, Xo), rel_err(Pg, Po)
+    ex, ep = rel_err(Xg, Xo), cov_err(Pg, Po)
     print(f"large n={n} {dtype}: rel err X {ex:.2e} P {ep:.2e}")
     assert max(ex, ep) < (REL_TOL if dtype == "f64" else F32_TOL)
     assert core.status(1) == 0 and core.dim(0) == 3
@@ -79,7 +81,7 @@ def test_replay_parity(L, T, kw, dtype, built):
         assert np.array_equal(dims.cpu().numpy()[b], do) and np.array_equal(Z, Zo)
         for a, c in zip(core.wait_list(b, cap=2048), o.wait_list()):
             assert np.array_equal(a, c)
-        errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), rel_err(P, Po)
+        errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), cov_err(P, Po)
         print(f"large replay L={L} {dtype} b={b} N={core.dim(b)}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < tol and core.status(b) == 0
 
@@ -106,7 +108,7 @@ def test_replay_parity_stream_groups(built):
         Xo, Zo, Po = o.state()
         X, Z, P = core.state(b)
         assert np.array_equal(dims.cpu().numpy()[b], do) and np.array_equal(Z, Zo)
-        errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), rel_err(P, Po)
+        errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), cov_err(P, Po)
         print(f"large replay groups b={b} N={core.dim(b)}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < REL_TOL and core.status(b) == 0
 
@@ -133,7 +135,7 @@ def test_config4_512_landmarks(built):
         torch.cuda.synchronize()
         X, Z, P = core.state(0)
         assert np.array_equal(dims.cpu().numpy()[0], do) and np.array_equal(Z, Zo) and core.status(0) == 0
-        errs = rel_err(poses.cpu().numpy()[0], po), rel_err(X, Xo), rel_err(P, Po)
+        errs = rel_err(poses.cpu().numpy()[0], po), rel_err(X, Xo), cov_err(P, Po)
         print(f"config 4 (n=1027) {'f32' if dtype == F32 else 'f64'}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < tol
 
@@ -153,6 +155,37 @@ def test_host_mirror_on_the_large_path(built):
     Xo, Zo, Po = o.state()
     X, Z, a00, a10 = node.state()
     assert dn[-1] == tg.full_dim(L) and np.array_equal(dn, do) and np.array_equal(Z, Zo) and (a00, a10) == o.A()
-    errs = rel_err(pn, po), rel_err(X, Xo), rel_err(node.P(), Po)
+    errs = rel_err(pn, po), rel_err(X, Xo), cov_err(node.P(), Po)
     print(f"host mirror on the large path N={dn[-1]}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
     assert max(errs) < REL_TOL
+
+
+def test_fp32_drift_over_2000_callbacks(built):
+    """configs[3] over a long horizon: the fp32 path against the fp64 path of the same library (itself within 1e-14 of the
+    oracle above) on one 512-landmark trace.  With P in binary64 the fp32 error does not random-walk: it must be within the
+    north-star 1e-6 (norm-wise and block-wise) at 2000 callbacks, and the state within 1e-8."""
+    import torch
+    from awesomeslam_amd.core import Core, F32, F64
+    from util import block_rel_err
+
+    L, T, B = 512, 2000, 1
+    tr = tg.make_traces(L, T, B=B, seed=4)
+    cores = {}
+    for name, dt in (("f32", F32), ("f64", F64)):
+        c = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=dt)
+        c.set_trace(tr)
+        cores[name] = c
+    scratch = torch.zeros((B, 500, 3), dtype=torch.float64, device="cuda")
+    for t0 in range(0, T, 500):
+        for k, c in cores.items():
+            c.replay(t0, 500, scratch.data_ptr(), None)
+        torch.cuda.synchronize()
+        X32, _, P32 = cores["f32"].state(0)
+        X64, _, P64 = cores["f64"].state(0)
+        eb = block_rel_err(P32, P64)
+        print(f"fp32 drift n={cores['f32'].dim(0)} t={t0 + 500}: X {rel_err(X32, X64):.2e}  P {rel_err(P32, P64):.2e}  "
+              f"blocks pose/cross/landmark {eb[0]:.2e} {eb[1]:.2e} {eb[2]:.2e}  asym {np.abs(P32 - P32.T).max():.1e}")
+    assert cores["f32"].dim(0) == 1027 and cores["f32"].status(0) == 0 and cores["f64"].status(0) == 0
+    assert rel_err(X32, X64) < 1e-8
+    assert cov_err(P32, P64) < REL_TOL
+    assert np.array_equal(P32, P32.T), "the fp32 update mirrors the lower triangle: P stays exactly symmetric"

@@ -1,0 +1,46 @@
+"""The build guard of tools/check_spill_exec.py: VGPR spill code ahead of the instruction that re-activates lanes in a block
+(hipcc, ROCm 7.2, gfx950: found as the cause of the round-1 "UKF chol(P) codegen hazard")."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+BAD = """
+_Z1kv:                                  ; @_Z1kv
+	s_mov_b64 s[0:1], exec
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+	v_add_u32_e32 v3, 0x300, v3
+	v_cmp_le_i32_e32 vcc, s16, v3
+	s_or_b64 s[4:5], vcc, s[4:5]
+	s_andn2_b64 exec, exec, s[4:5]
+	s_cbranch_execnz .LBB0_1
+.LBB0_2:
+	s_movk_i32 s17, 0xff80
+	s_waitcnt vmcnt(0)
+	scratch_store_dwordx2 off, v[68:69], off offset:88 ; 8-byte Folded Spill
+	s_or_b64 exec, exec, s[0:1]
+	s_endpgm
+"""
+GOOD = BAD.replace("	scratch_store_dwordx2 off, v[68:69], off offset:88 ; 8-byte Folded Spill\n	s_or_b64 exec, exec, s[0:1]\n",
+                   "	s_or_b64 exec, exec, s[0:1]\n	scratch_store_dwordx2 off, v[68:69], off offset:88 ; 8-byte Folded Spill\n")
+
+
+def test_detector_on_the_pattern_found(tmp_path):
+    import check_spill_exec as g
+
+    for name, text, want in (("bad.s", BAD, 1), ("good.s", GOOD, 0)):
+        p = tmp_path / name
+        p.write_text(text)
+        f = g.scan(str(p))
+        assert len(f) == want, f
+    assert "EXEC == 0" in g.scan(str(tmp_path / "bad.s"))[0][2]
+
+
+def test_product_assembly_is_clean():
+    """the device assembly of the product library, compiled with the product flags (hipcc cross-compiles without a GPU)"""
+    csrc = os.path.join(ROOT, "awesomeslam_amd", "csrc")
+    r = subprocess.run(["make", "-s", "-C", csrc, "check-spills"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    assert b"check_spill_exec: clean" in r.stdout
