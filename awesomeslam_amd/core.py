@@ -22,7 +22,7 @@ ST_GROWTH_REFUSED, ST_WAIT_OVERFLOW, ST_NOT_PD, ST_OBS_OVERFLOW = 1, 2, 4, 8
 # every symbol include/aslam_core.h declares (tests check the library exports them all)
 CORE_SYMBOLS = (
     "aslam_create", "aslam_destroy", "aslam_reset", "aslam_last_error", "aslam_abi_version", "aslam_set_state",
-    "aslam_grow", "aslam_ekf_step", "aslam_ukf_step", "aslam_set_trace", "aslam_replay", "aslam_get_dim",
+    "aslam_grow", "aslam_ekf_step", "aslam_ukf_step", "aslam_ekf_step_batch", "aslam_ukf_step_batch", "aslam_set_trace", "aslam_replay", "aslam_get_dim",
     "aslam_get_state", "aslam_get_A", "aslam_get_landmarks", "aslam_get_wait", "aslam_get_status",
     "aslam_get_layout", "aslam_kernel_info",
 )
@@ -93,6 +93,8 @@ def core_lib():
         L.aslam_grow.argtypes = [vp, ci, ci, pd, pd]
         L.aslam_ekf_step.argtypes = [vp, ci, cf, cf, cf, pd, cd, cd, pd, vp]
         L.aslam_ukf_step.argtypes = [vp, ci, cf, cf, cf, pd, pd, vp]
+        L.aslam_ekf_step_batch.argtypes = [vp, pf, pf, pf, pd, ci, pd, pd, pd, ci, vp]
+        L.aslam_ukf_step_batch.argtypes = [vp, pf, pf, pf, pd, ci, pd, ci, vp]
         L.aslam_set_trace.argtypes = [vp, ctypes.POINTER(TraceView)]
         L.aslam_replay.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp]
         L.aslam_get_dim.argtypes = [vp, ci, pi]
@@ -312,6 +314,26 @@ class Core:
         _chk(core_lib().aslam_ukf_step(self._h, traj, float(np.float32(vx)), float(np.float32(az)), float(np.float32(dt)),
                                        _ptr(Z, ctypes.c_double), _ptr(X, ctypes.c_double), stream))
         return X
+
+    def step_batch(self, vx, az, dt, Z, a00=None, a10=None, X_out=None, stream=None):
+        """slam() for all filters of the context in one launch chain.  vx, az, dt: [batch] float32; Z: [batch, ldz] float64;
+        a00, a10: [batch] float64 (EKF).  Asynchronous: the arrays are used until `stream` is synchronised; X_out ([batch, ldx]
+        float64, optional) is valid only after that.  Arrays are taken as they are (no copies): pass C-contiguous ones."""
+        for a, t in ((vx, np.float32), (az, np.float32), (dt, np.float32), (Z, np.float64)):
+            assert a.dtype == t and a.flags.c_contiguous and a.shape[0] == self.batch
+        ldx = 0 if X_out is None else X_out.shape[1]
+        if self.filter == "ekf":
+            assert a00.dtype == np.float64 and a10.dtype == np.float64
+            _chk(core_lib().aslam_ekf_step_batch(self._h, _ptr(vx, ctypes.c_float), _ptr(az, ctypes.c_float), _ptr(dt, ctypes.c_float),
+                                                 _ptr(Z, ctypes.c_double), Z.shape[1], _ptr(a00, ctypes.c_double), _ptr(a10, ctypes.c_double),
+                                                 _ptr(X_out, ctypes.c_double), ldx, stream))
+        else:
+            _chk(core_lib().aslam_ukf_step_batch(self._h, _ptr(vx, ctypes.c_float), _ptr(az, ctypes.c_float), _ptr(dt, ctypes.c_float),
+                                                 _ptr(Z, ctypes.c_double), Z.shape[1], _ptr(X_out, ctypes.c_double), ldx, stream))
+
+    def sync(self, stream=None):
+        import torch
+        torch.cuda.synchronize() if stream is None else torch.cuda.ExternalStream(stream).synchronize()
 
     # ---- replay seam
     def set_trace(self, trace):

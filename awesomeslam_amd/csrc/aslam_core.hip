@@ -64,12 +64,13 @@ struct aslam_ctx
         LargeView<double> lv64 = {};
         LargeView<float> lv32 = {};
         int *skipped = nullptr;
+        float *step_in = nullptr; // [3][batch] vx, az, dt of a batched step
         double *largeP = nullptr; // = lv64.P or lv32.P: the covariance is binary64 in both modes
         // replay splits the batch into groups that run the launch chain side by side on separate streams: the latency-bound
         // launches of one group (one-wave diagonal factorisations, the front end, short-K panels) then overlap the GEMMs of
         // the others
-        static constexpr int LARGE_GROUPS = 4;
-        int large_groups = LARGE_GROUPS; // ASLAM_LARGE_GROUPS=1..4 overrides (1 = a single stream, for per-kernel profiling)
+        static constexpr int LARGE_GROUPS = 8; // capacity; the default below was chosen by measurement (profiles/)
+        int large_groups = 4;                  // ASLAM_LARGE_GROUPS=1..8 overrides (1 = a single stream, for per-kernel profiling)
         hipStream_t aux[LARGE_GROUPS - 1] = {};
         hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
 };
@@ -248,7 +249,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         const size_t lds = LargeLds::bytes(NP);
         auto fk = large_frontend_kernel<T, MODE>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int Bz = (MODE == MODE_STEP) ? 1 : c->cfg.batch;
+        const int Bz = (MODE == MODE_STEP && sa.traj >= 0) ? 1 : c->cfg.batch; // sa.traj < 0: the batched step
         (void)grid;
         // the kernels index the filter through blockIdx: a group of filters starting at b0 gets views shifted to b0
         struct Group
@@ -275,6 +276,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 g.dv.wait_rb += b * (size_t)c->dv.max_wait * 2;
                 g.dv.wait_cnt += b * (size_t)c->dv.max_wait;
                 g.dv.wait_n += b;
+                g.dv.step_in += b; // [3][B]: the stride stays the whole batch
                 if (MODE == MODE_REPLAY && b0 > 0)
                 {
                         g.dv.tr_pose += 2 * b * T_;
@@ -314,7 +316,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                 if (k + 1 < NB)
                                         hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                         }
-                        hipLaunchKernelGGL(large_trsm_resident<LARGE_NB_MAX>, dim3(NB, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                        hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(NB, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                         hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 else
@@ -330,7 +332,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                    g.dims, g.skip);
         };
         const int NG = c->large_groups;
-        if (MODE == MODE_STEP)
+        if (MODE == MODE_STEP && sa.traj >= 0)
         {
                 Group g = make_group(sa.traj, 1, st);
                 sa.traj = 0;
@@ -519,6 +521,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                 }
         }
         A_(dev_alloc(c, &d.A, B * 2, c->owned));
+        A_(dev_alloc(c, &c->step_in, B * 3, c->owned));
+        d.step_in = c->step_in;
         A_(dev_alloc(c, &d.n, B, c->owned));
         A_(dev_alloc(c, &d.flags, B, c->owned));
         A_(dev_alloc(c, &d.status, B, c->owned));
@@ -709,6 +713,58 @@ int aslam_ukf_step(aslam_ctx *c, int traj, float vx, float az, float dt, const d
                 HIP_TRY(hipStreamSynchronize(st));
         }
         return ASLAM_OK;
+}
+
+namespace
+{
+/// the batched per-callback seam: inputs of all filters to the device (asynchronously, straight from the caller's arrays), one launch
+/// chain for the whole batch, optional read-back of X; no synchronisation
+int step_batch(aslam_ctx *c, int filter, const float *vx, const float *az, const float *dt, const double *Z, int ldz, const double *a00,
+               const double *a10, double *X_out, int ldx, void *stream)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        if (c->cfg.filter != filter)
+                return fail(ASLAM_ERR_STATE, "context was created for the other filter");
+        if (!vx || !az || !dt || !Z || (filter == ASLAM_EKF && (!a00 || !a10)))
+                return fail(ASLAM_ERR_ARG, "vx, az, dt, Z (and a00, a10 for the EKF) are required");
+        const int B = c->cfg.batch, NP = c->NP;
+        if (ldz < 3 || (X_out && ldx < 3))
+                return fail(ASLAM_ERR_ARG, "row strides must cover the state");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        c->last_stream = st;
+        DevView &d = c->dv;
+        HIP_TRY(hipMemcpyAsync(c->step_in, vx, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->step_in + B, az, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->step_in + 2 * (size_t)B, dt, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        const size_t wz = sizeof(double) * (size_t)std::min(ldz, NP);
+        HIP_TRY(hipMemcpy2DAsync(d.Z, sizeof(double) * NP, Z, sizeof(double) * ldz, wz, B, hipMemcpyHostToDevice, st));
+        if (filter == ASLAM_EKF)
+        {
+                HIP_TRY(hipMemcpy2DAsync(d.A, 2 * sizeof(double), a00, sizeof(double), sizeof(double), B, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpy2DAsync(d.A + 1, 2 * sizeof(double), a10, sizeof(double), sizeof(double), B, hipMemcpyHostToDevice, st));
+        }
+        StepArgs sa{-1, 0.f, 0.f, 0.f};
+        int rc = launch<MODE_STEP>(c, B, 0, 1, nullptr, nullptr, sa, st);
+        if (rc != ASLAM_OK)
+                return rc;
+        if (X_out)
+                HIP_TRY(hipMemcpy2DAsync(X_out, sizeof(double) * ldx, d.X, sizeof(double) * NP, sizeof(double) * (size_t)std::min(ldx, NP), B,
+                                         hipMemcpyDeviceToHost, st));
+        return ASLAM_OK;
+}
+} // namespace
+
+int aslam_ekf_step_batch(aslam_ctx *c, const float *vx, const float *az, const float *dt, const double *Z, int ldz, const double *a00,
+                         const double *a10, double *X_out, int ldx, void *stream)
+{
+        return step_batch(c, ASLAM_EKF, vx, az, dt, Z, ldz, a00, a10, X_out, ldx, stream);
+}
+
+int aslam_ukf_step_batch(aslam_ctx *c, const float *vx, const float *az, const float *dt, const double *Z, int ldz, double *X_out, int ldx,
+                         void *stream)
+{
+        return step_batch(c, ASLAM_UKF, vx, az, dt, Z, ldz, nullptr, nullptr, X_out, ldx, stream);
 }
 
 int aslam_set_trace(aslam_ctx *c, const aslam_trace *tr)
@@ -1056,7 +1112,7 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
         if (c->large)
         {
                 if (c->cfg.dtype == ASLAM_F32)
-                        std::snprintf(buf, sizeof(buf), "large_trsm_resident<%d> + large_syrk_f32p64 (%d-launch chain per callback, %d stream groups)",
+                        std::snprintf(buf, sizeof(buf), "large_trsm_pipe<%d> + large_syrk_f32p64 (%d-launch chain per callback, %d stream groups)",
                                       (int)LARGE_NB_MAX, 4 + 2 * (c->NP / LB), c->large_groups);
                 else
                         std::snprintf(buf, sizeof(buf), "large_update_panel<double> (%d-launch chain per callback, %d stream groups)",

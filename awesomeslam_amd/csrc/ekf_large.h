@@ -156,7 +156,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         SmallShared &sm = *L.sm;
         double *const sX = L.sX, *const sZ = L.sZ;
         const int tid = threadIdx.x;
-        const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
+        const int b = (MODE == MODE_STEP && sa.traj >= 0) ? sa.traj : (int)blockIdx.x; // sa.traj < 0: the batched step, one workgroup per filter
         double *Pg = lv.P + (size_t)b * NP * NP;
         double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
         double *Yg = lv.Y + (size_t)b * NP;
@@ -182,9 +182,10 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         {
                 if (tid == 0)
                 {
-                        sm.vx = sa.vx;
-                        sm.az = sa.az;
-                        sm.dt = sa.dt;
+                        // one filter: the arguments of the call; batched step: this filter's entries of the per-call arrays
+                        sm.vx = sa.traj >= 0 ? sa.vx : d.step_in[b];
+                        sm.az = sa.traj >= 0 ? sa.az : d.step_in[d.B + b];
+                        sm.dt = sa.traj >= 0 ? sa.dt : d.step_in[2 * d.B + b];
                 }
                 __syncthreads();
         }
@@ -416,22 +417,13 @@ __device__ __forceinline__ double rsqrt_fast(double x)
         return rsqrt_newton(x);
 }
 
-/// Cholesky of the 64x64 diagonal block k of S in place (lower; the strict upper part is zeroed) and the inverse of the
-/// factor -> Linv, by ONE wave with the block in registers: lane i holds row i, column entries of other rows are
+/// Cholesky of a 64x64 diagonal block of S in place (lower; the strict upper part is zeroed) and the inverse of the
+/// factor -> Li, by ONE wave with the block in registers: lane i holds row i, column entries of other rows are
 /// broadcast with v_readlane, so the 64 dependent column steps run without LDS or barriers.  The inverse (lane c carries
 /// column c of L^-1) lets the panel below the block be eliminated as a matrix product on the MFMA unit (X L^-T = X Linv^T).
-/// grid (B), 64 threads.
-template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevView d, LargeView<T> lv, int k, const int *skipped)
+/// S: first element of the block (row stride NP).  Returns false on a non-positive pivot.
+template <typename T> __device__ __forceinline__ bool large_potrf_block(T *S, int NP, T *Li, int lane)
 {
-        const int b = blockIdx.x;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        if (k >= large_blocks(n))
-                return;
-        T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
-        T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
-        const int lane = threadIdx.x;
         typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
         constexpr int VW = 16 / sizeof(T);
         T a[LB];
@@ -484,7 +476,23 @@ template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevV
 #pragma unroll
         for (int r = 0; r < LB; ++r)
                 Li[r * LB + lane] = sres[r];
-        if (bad && lane == 0)
+        return !bad;
+}
+
+/// Diagonal block k.  grid (B), 64 threads.  (Folding this into the tail of large_update_panel(k-1) was tried: inlined there the
+/// broadcasts spill 1 500 SGPRs and the panel kernel drops from 3 to 2 waves per SIMD; profiles/r02_experiments.md.)
+template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevView d, LargeView<T> lv, int k, const int *skipped)
+{
+        const int b = blockIdx.x;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        if (k >= large_blocks(n))
+                return;
+        T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
+        T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
+        const int lane = threadIdx.x;
+        if (!large_potrf_block(S, NP, Li, lane) && lane == 0)
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
 }
 
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(256) void large_update_panel(DevView d, LargeView<T
         const int n = d.n[b], NP = lv.NP;
         const int nb = large_blocks(n), na = nb * LB;
         const int rt0 = k0 + 1 + 2 * blockIdx.x; // first virtual 64-row block: S rows below the diagonal block, then all of G
-        const int vlim = s_only ? nb : 2 * nb;    // s_only: the rows of G are solved by large_trsm_resident instead
+        const int vlim = s_only ? nb : 2 * nb;    // s_only: the rows of G are solved by large_trsm_pipe instead
         if (k0 >= nb || rt0 >= vlim)
                 return;
         const bool two = rt0 + 1 < vlim; // the last workgroup may have a single block

@@ -14,27 +14,18 @@
 // floats of a row of L, i.e. ONE 16-byte LDS read feeds four MFMAs, and no accumulator is ever moved, transposed or
 // re-read.  (The contraction index is visited in a permuted order; both operands use the same permutation.)
 //
-// The 64x64 blocks of L -- L(k, 0) .. L(k, k-1), then Linv_k -- are shared by the four waves of a workgroup and stream
-// through two LDS buffers (register prefetch one block ahead, one barrier per block).  Register indices must be static: the
-// sweep runs as two run-time loops (block column k, history block j) around a 17-way wave-uniform switch on j whose cases are
-// the 64 MFMAs against strip tiles 4 j .. 4 j + 3 -- 12 KB of code that stays in the instruction cache (the first version
-// unrolled all 153 blocks: 150 KB of straight-line code, every line an instruction-cache miss, 55 % of the MFMA rate).
-// One workgroup per CU (the strip needs most of the register file), 64 MFMAs per wave between barriers.
-// n^3 flops like any triangular solve with n right-hand sides, plus the 64-deep Linv products.
+// The 64x64 blocks of L -- Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ... -- are shared by the four waves of a workgroup and
+// stream through three LDS buffers (large_trsm_pipe below).  Register indices must be static, and with ONE wave per SIMD nothing hides
+// a taken branch: the history blocks of a block column are a fall-through chain (template recursion over the block index) whose only
+// taken branch is its exit -- 14 KB of code that stays in the instruction cache.  One workgroup per CU (the strip needs most of the
+// register file), 64 MFMAs per wave and block.  n^3 flops like any triangular solve with n right-hand sides, plus the 64-deep Linv
+// products.  What the earlier forms cost (profiles/r02_experiments.md section 3, tools/ubench/trsm_bench.hip; cycles per MFMA and
+// wave, 32 = the pipe's rate): 153 blocks unrolled 55 (instruction-cache misses), loops + switch 51, chain 46, this file 44.
 #pragma once
 
 namespace aslam
 {
 constexpr int TRSM_LDT = LB + 8; // LDS row stride in floats: 18 sixteen-byte slots -> conflict-free ds_read_b128 operand reads
-
-/// global -> registers: this thread's share (4 x 16 bytes) of a 64x64 block with row stride `ld`
-__device__ __forceinline__ void trsm_fetch(f4 (&pf)[4], const float *blk, int ld, int tid)
-{
-        const int r0 = tid >> 4, c4 = (tid & 15) * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-                pf[q] = *reinterpret_cast<const f4 *>(blk + (size_t)(r0 + 16 * q) * ld + c4);
-}
 
 /// registers -> LDS buffer [64][TRSM_LDT]
 __device__ __forceinline__ void trsm_stash(float *buf, const f4 (&pf)[4], int tid)
@@ -78,19 +69,12 @@ template <int T> __device__ __forceinline__ void trsm_mfma_tile(f4 &c0, f4 &c1, 
                        "n"(4 * T + 3));
 }
 
-/// c[t] += L(k, J)(rows 16 t ..) * W(tiles 4 J .. 4 J + 3): the 64 MFMAs of one history block
-template <int J> __device__ __forceinline__ void trsm_history(f4 (&c)[4], const float *buf, int a_off)
+/// the four 16-byte fragments (row tiles t = 0 .. 3) of column tile q of a staged 64x64 block
+__device__ __forceinline__ void trsm_frags(f4 (&a)[4], const float *buf, int a_off, int q)
 {
-        f4 a[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                        a[q][t] = *reinterpret_cast<const f4 *>(buf + a_off + 16 * t * TRSM_LDT + 16 * q);
-        trsm_mfma_tile<4 * J + 0>(c[0], c[1], c[2], c[3], a[0][0], a[0][1], a[0][2], a[0][3]);
-        trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a[1][0], a[1][1], a[1][2], a[1][3]);
-        trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a[2][0], a[2][1], a[2][2], a[2][3]);
-        trsm_mfma_tile<4 * J + 3>(c[0], c[1], c[2], c[3], a[3][0], a[3][1], a[3][2], a[3][3]);
+        for (int t = 0; t < 4; ++t)
+                a[t] = *reinterpret_cast<const f4 *>(buf + a_off + 16 * t * TRSM_LDT + 16 * q);
 }
 
 /// x[tp] += Linv(tile tp, tile t) * C(tile t) for tp = t .. 3 (Linv is lower triangular in tiles): B operand = c in VGPRs
@@ -138,28 +122,6 @@ __device__ __forceinline__ void trsm_mfma_x(f4 &x0, f4 &x1, f4 &x2, f4 &x3, cons
                              : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
 }
 
-/// X = Linv C for one block column (four accumulators in flight), V tile stores; returns X in x[]
-__device__ __forceinline__ void trsm_solve_block(f4 (&x)[4], const f4 (&c)[4], const float *buf, int a_off, float *vout)
-{
-        f4 a[4][4]; // a[t][i]: fragment of Linv tile (row tile t + i, column tile t)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 4 - t; ++i)
-                        a[t][i] = *reinterpret_cast<const f4 *>(buf + a_off + 16 * (t + i) * TRSM_LDT + 16 * t);
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp)
-                x[tp] = (f4){0.f, 0.f, 0.f, 0.f};
-        trsm_mfma_x<4>(x[0], x[1], x[2], x[3], a[0][0], a[0][1], a[0][2], a[0][3], c[0]);
-        trsm_mfma_x<3>(x[0], x[1], x[2], x[3], a[1][0], a[1][1], a[1][2], a[1][2], c[1]);
-        trsm_mfma_x<2>(x[0], x[1], x[2], x[3], a[2][0], a[2][1], a[2][1], a[2][1], c[2]);
-        trsm_mfma_x<1>(x[0], x[1], x[2], x[3], a[3][0], a[3][0], a[3][0], a[3][0], c[3]);
-        asm volatile("s_nop 15" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); // MFMA result -> store data
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-                *reinterpret_cast<f4 *>(vout + 16 * t) = x[t];
-}
-
 /// strip tiles 4 K .. 4 K + 3 <- x
 template <int K> __device__ __forceinline__ void trsm_keep(const f4 (&x)[4])
 {
@@ -178,12 +140,93 @@ template <int K> __device__ __forceinline__ void trsm_keep(const f4 (&x)[4])
                        "n"(16 * K + 14), "n"(16 * K + 15));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// large_trsm_pipe: the sweep, software-pipelined ACROSS the per-block barrier.  With two LDS buffers and the barrier at the end of a
+// block, every block starts with eight LDS reads whose latency nothing hides (one wave per SIMD, and the four waves of the workgroup
+// issue their reads in the same cycles: ~300 of a block's ~2 350 cycles).  Here the blocks go through THREE LDS buffers: block i + 2
+// is written while block i is multiplied, so block i + 1 is already visible and its first two fragment sets are read behind the last
+// MFMAs of block i; the barrier sits 16 MFMAs behind the LDS traffic it waits for.
+
+/// branch-free cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ...  (clamped at the end: the last
+/// blocks are fetched again, which is harmless)
+struct TrsmSeq
+{
+        int k, j, nb, NP;
+        const float *Sb, *Linv;
+        int r0, c4; // this thread's 16 bytes of a block: rows r0 + 16 q, columns c4 .. c4 + 3
+        __device__ __forceinline__ void fetch(f4 (&pf)[4])
+        {
+                const int kk = min(k, nb - 1);
+                const bool hist = j < kk;
+                // wave-uniform row bases (scalar registers) + one 32-bit lane offset: no 64-bit vector arithmetic per block
+                const float *blk = hist ? Sb + (size_t)(LB * kk) * NP + LB * j : Linv + (size_t)kk * LB * LB;
+                const int ld = hist ? NP : LB;
+                const unsigned off = (unsigned)(r0 * ld + c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                        pf[q] = *reinterpret_cast<const f4 *>(blk + (size_t)(16 * q * ld) + off);
+                j = hist ? j + 1 : 0;
+                k = hist ? k : k + 1;
+        }
+};
+
+struct TrsmPipe
+{
+        float *cur, *nxt, *far; // LDS buffers of block i, i + 1, i + 2
+        __device__ __forceinline__ void rotate()
+        {
+                float *t = cur;
+                cur = nxt;
+                nxt = far;
+                far = t;
+        }
+};
+
+/// one history block with fragments a0 (column tile 0) and a1 (column tile 1) of it already in registers; leaves a0 / a1 of the NEXT block
+template <int J, int DIAG>
+__device__ __forceinline__ void trsm_history_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&a1)[4], f4 (&pf)[4], TrsmPipe &pp, TrsmSeq &seq, int a_off, int tid)
+{
+        trsm_mfma_tile<4 * J + 0>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
+        trsm_frags(a0, pp.cur, a_off, 2);
+        asm volatile("" ::: "memory");
+        trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
+        trsm_frags(a1, pp.cur, a_off, 3); // the last read of buffer `cur`
+        // block i + 2 -> LDS (fetched while block i - 1 was multiplied), block i + 3 -> registers
+        if constexpr (!(DIAG & 2))
+                trsm_stash(pp.far, pf, tid);
+        if constexpr (!(DIAG & 1))
+                seq.fetch(pf);
+        asm volatile("" ::: "memory");
+        trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
+        // the barrier of this block sits HERE, 16 MFMAs behind the LDS traffic it has to wait for: block i + 2 becomes visible (first read
+        // behind the third MFMA group of block i + 1), and buffer `cur` is free for block i + 3 (written behind the second group of block i + 1)
+        if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the barrier -- racy)
+                __syncthreads();
+        trsm_frags(a0, pp.nxt, a_off, 0);
+        asm volatile("" ::: "memory");
+        trsm_mfma_tile<4 * J + 3>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
+        trsm_frags(a1, pp.nxt, a_off, 1);
+        asm volatile("" ::: "memory");
+        pp.rotate();
+}
+
+template <int J, int DIAG>
+__device__ __forceinline__ void trsm_chain_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&a1)[4], f4 (&pf)[4], int k, TrsmPipe &pp, TrsmSeq &seq, int a_off, int tid)
+{
+        if (J < k)
+        {
+                trsm_history_pipe<J, DIAG>(c, a0, a1, pf, pp, seq, a_off, tid);
+                if constexpr (J + 1 < LARGE_NB_MAX - 1)
+                        trsm_chain_pipe<J + 1, DIAG>(c, a0, a1, pf, k, pp, seq, a_off, tid);
+        }
+}
+
 /// grid (NP / 64, B), 256 threads; wave w of workgroup x owns rows [64 x + 16 w, +16) of G.  In place: G -> V.
-template <int NBMAX>
-__global__ __launch_bounds__(256, 1) void large_trsm_resident(DevView d, LargeView<float> lv, const int *skipped)
+template <int NBMAX, int DIAG = 0>
+__global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<float> lv, const int *skipped)
 {
         static_assert(NBMAX == 17, "the switch below lists 17 block columns");
-        __shared__ __attribute__((aligned(16))) float lds[2][LB * TRSM_LDT];
+        __shared__ __attribute__((aligned(16))) float lds[3][LB * TRSM_LDT];
         const int b = blockIdx.y;
         if (skipped[b])
                 return;
@@ -193,114 +236,111 @@ __global__ __launch_bounds__(256, 1) void large_trsm_resident(DevView d, LargeVi
                 return;
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * blockIdx.x + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
-        const float *Sb = lv.S + (size_t)b * NP * NP;
-        const float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
-        // LDS read offset of this lane's A fragments: row 16 t + li, sixteen-byte slot 4 q + lg
         const int a_off = li * TRSM_LDT + 4 * lg;
-
-        // the strip: a0 .. a255 (tiles 0 .. 63; the last block column is never a history block).  Naming them as clobbers here is what
-        // makes the kernel descriptor allocate them; nothing of the compiler's lives in an AGPR (all MFMAs are inline assembly on VGPRs)
-        asm volatile("" ::: "a0", "a255");
-        f4 pf[4];
-        // block sequence: for k: L(k,0) .. L(k,k-1), Linv_k.  Block 0 is Linv_0.
-        trsm_fetch(pf, Linv, LB, tid);
-        trsm_stash(lds[0], pf, tid);
+        asm volatile("" ::: "a0", "a255"); // the strip (see above)
+        unsigned long long t0_ = 0, r0_ = 0;
+        if constexpr (DIAG & 8)
+        {
+                t0_ = __builtin_amdgcn_s_memtime();
+                r0_ = __builtin_amdgcn_s_memrealtime();
+        }
+        TrsmSeq seq = {0, 0, nb, NP, lv.S + (size_t)b * NP * NP, lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB, tid >> 4, (tid & 15) * 4};
+        TrsmPipe pp = {lds[0], lds[1], lds[2]};
+        f4 pf[4], a0[4], a1[4], c[4], g0[4];
+        seq.fetch(pf);
+        trsm_stash(pp.cur, pf, tid);
+        seq.fetch(pf);
+        trsm_stash(pp.nxt, pf, tid);
+        seq.fetch(pf); // block 2: written to LDS during block 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+        {
+                c[t] = (f4){0.f, 0.f, 0.f, 0.f};
+                g0[t] = *reinterpret_cast<const f4 *>(Grow + 16 * t); // G[row][16 t + 4 lg .. +3]
+        }
         __syncthreads();
-        int cur = 0;
+        trsm_frags(a0, pp.cur, a_off, 0);
+        trsm_frags(a1, pp.cur, a_off, 1);
 #pragma unroll 1
         for (int k = 0; k < nb; ++k)
         {
-                f4 c[4], g0[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                {
-                        c[t] = (f4){0.f, 0.f, 0.f, 0.f};
-                        g0[t] = *reinterpret_cast<const f4 *>(Grow + LB * k + 16 * t); // G[row][64 k + 16 t + 4 lg .. +3]
-                }
-#pragma unroll 1
-                for (int jb = 0; jb < k; ++jb)
-                {
-                        // prefetch the next block: L(k, jb+1), or Linv_k after the last history block
-                        if (jb + 1 < k)
-                                trsm_fetch(pf, Sb + (size_t)(LB * k) * NP + LB * (jb + 1), NP, tid);
-                        else
-                                trsm_fetch(pf, Linv + (size_t)k * LB * LB, LB, tid);
-                        const float *buf = lds[cur];
-                        switch (jb)
-                        {
-#define ASLAM_TRSM_CASE(J)                                                                                             \
-        case J:                                                                                                        \
-                trsm_history<J>(c, buf, a_off);                                                                     \
-                break;
-                                ASLAM_TRSM_CASE(0)
-                                ASLAM_TRSM_CASE(1)
-                                ASLAM_TRSM_CASE(2)
-                                ASLAM_TRSM_CASE(3)
-                                ASLAM_TRSM_CASE(4)
-                                ASLAM_TRSM_CASE(5)
-                                ASLAM_TRSM_CASE(6)
-                                ASLAM_TRSM_CASE(7)
-                                ASLAM_TRSM_CASE(8)
-                                ASLAM_TRSM_CASE(9)
-                                ASLAM_TRSM_CASE(10)
-                                ASLAM_TRSM_CASE(11)
-                                ASLAM_TRSM_CASE(12)
-                                ASLAM_TRSM_CASE(13)
-                                ASLAM_TRSM_CASE(14)
-                        default:
-                                trsm_history<15>(c, buf, a_off);
-                                break;
-#undef ASLAM_TRSM_CASE
-                        }
-                        trsm_stash(lds[cur ^ 1], pf, tid);
-                        __syncthreads();
-                        cur ^= 1;
-                }
-                // C = G - history
+                trsm_chain_pipe<0, DIAG>(c, a0, a1, pf, k, pp, seq, a_off, tid);
+                // ---- the closing block of column k: C = G - history, X = Linv_k C (a0 = tiles (t, 0), a1 = tiles (t, 1) of Linv_k)
                 asm volatile("s_nop 15" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); // MFMA result -> VALU read
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                         c[t] = g0[t] - c[t];
-                // prefetch the first history block of the next block column (if there is one)
-                const bool more = (k + 1 < nb);
-                if (more)
-                        trsm_fetch(pf, Sb + (size_t)(LB * (k + 1)) * NP, NP, tid);
-                // X = Linv_k C, stored to V, and kept as strip tiles 4 k .. 4 k + 3 (static register names: a switch on the block column)
+                asm volatile("s_nop 4" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); // VALU result -> MFMA operand
+                f4 x[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        x[t] = (f4){0.f, 0.f, 0.f, 0.f};
+                trsm_mfma_x<4>(x[0], x[1], x[2], x[3], a0[0], a0[1], a0[2], a0[3], c[0]);
+                // fragments (2,2), (3,2), (3,3) of Linv_k
+                a0[2] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 32 * TRSM_LDT + 32);
+                a0[3] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 32);
+                a0[0] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 48);
+                asm volatile("" ::: "memory");
+                if constexpr (!(DIAG & 2))
+                        trsm_stash(pp.far, pf, tid);
+                if constexpr (!(DIAG & 1))
+                        seq.fetch(pf);
+                trsm_mfma_x<3>(x[0], x[1], x[2], x[3], a1[1], a1[2], a1[3], a1[3], c[1]);
+                if constexpr (!(DIAG & 2) && !(DIAG & 16))
+                        __syncthreads(); // as in trsm_history_pipe: behind 12 MFMAs
+                trsm_mfma_x<2>(x[0], x[1], x[2], x[3], a0[2], a0[3], a0[3], a0[3], c[2]);
+                trsm_frags(a1, pp.nxt, a_off, 1);
+                asm volatile("" ::: "memory");
+                trsm_mfma_x<1>(x[0], x[1], x[2], x[3], a0[0], a0[0], a0[0], a0[0], c[3]);
+                // the first fragments of the next block (history block 0 of column k + 1)
+                trsm_frags(a0, pp.nxt, a_off, 0);
+                asm volatile("s_nop 15" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); // MFMA result -> store data
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        *reinterpret_cast<f4 *>(Grow + LB * k + 16 * t) = x[t];
+                switch (k)
                 {
-                        f4 x[4];
-                        trsm_solve_block(x, c, lds[cur], a_off, Grow + LB * k);
-                        switch (k)
-                        {
 #define ASLAM_TRSM_KEEP(K)                                                                                             \
         case K:                                                                                                        \
                 trsm_keep<K>(x);                                                                                       \
                 break;
-                                ASLAM_TRSM_KEEP(0)
-                                ASLAM_TRSM_KEEP(1)
-                                ASLAM_TRSM_KEEP(2)
-                                ASLAM_TRSM_KEEP(3)
-                                ASLAM_TRSM_KEEP(4)
-                                ASLAM_TRSM_KEEP(5)
-                                ASLAM_TRSM_KEEP(6)
-                                ASLAM_TRSM_KEEP(7)
-                                ASLAM_TRSM_KEEP(8)
-                                ASLAM_TRSM_KEEP(9)
-                                ASLAM_TRSM_KEEP(10)
-                                ASLAM_TRSM_KEEP(11)
-                                ASLAM_TRSM_KEEP(12)
-                                ASLAM_TRSM_KEEP(13)
-                                ASLAM_TRSM_KEEP(14)
-                                ASLAM_TRSM_KEEP(15)
-                        default:
-                                break; // the last block column is never a history block
+                        ASLAM_TRSM_KEEP(0)
+                        ASLAM_TRSM_KEEP(1)
+                        ASLAM_TRSM_KEEP(2)
+                        ASLAM_TRSM_KEEP(3)
+                        ASLAM_TRSM_KEEP(4)
+                        ASLAM_TRSM_KEEP(5)
+                        ASLAM_TRSM_KEEP(6)
+                        ASLAM_TRSM_KEEP(7)
+                        ASLAM_TRSM_KEEP(8)
+                        ASLAM_TRSM_KEEP(9)
+                        ASLAM_TRSM_KEEP(10)
+                        ASLAM_TRSM_KEEP(11)
+                        ASLAM_TRSM_KEEP(12)
+                        ASLAM_TRSM_KEEP(13)
+                        ASLAM_TRSM_KEEP(14)
+                        ASLAM_TRSM_KEEP(15)
+                default:
+                        break; // the last block column is never a history block
 #undef ASLAM_TRSM_KEEP
-                        }
                 }
-                if (more)
+                // next block column: fresh accumulators, its slice of G (consumed k + 1 blocks from now)
+                const int kn = min(k + 1, nb - 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
                 {
-                        trsm_stash(lds[cur ^ 1], pf, tid);
-                        __syncthreads();
-                        cur ^= 1;
+                        c[t] = (f4){0.f, 0.f, 0.f, 0.f};
+                        g0[t] = *reinterpret_cast<const f4 *>(Grow + LB * kn + 16 * t);
+                }
+                pp.rotate();
+        }
+        if constexpr (DIAG & 8)
+        {
+                if (tid == 0)
+                {
+                        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                        lv.Y[2 * wg] = (double)(__builtin_amdgcn_s_memtime() - t0_);
+                        lv.Y[2 * wg + 1] = (double)(__builtin_amdgcn_s_memrealtime() - r0_);
                 }
         }
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
         SmallShared &sm = *L.sm;
 
         const int tid_launch = threadIdx.x, tid = tid_launch;
-        const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
+        const int b = (MODE == MODE_STEP && sa.traj >= 0) ? sa.traj : (int)blockIdx.x; // sa.traj < 0: the batched step, one workgroup per filter
         double *Pg = d.P + (size_t)b * NP * NP;
         const double r_meas = (double)KR, q_proc = (double)KQ;
 #ifdef ASLAM_STAMPS
@@ -140,9 +140,10 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 {
                         if (tid == 0)
                         {
-                                sm.vx = sa.vx;
-                                sm.az = sa.az;
-                                sm.dt = sa.dt;
+                                // one filter: the arguments of the call; batched step: this filter's entries of the per-call arrays
+                                sm.vx = sa.traj >= 0 ? sa.vx : d.step_in[b];
+                                sm.az = sa.traj >= 0 ? sa.az : d.step_in[d.B + b];
+                                sm.dt = sa.traj >= 0 ? sa.dt : d.step_in[2 * d.B + b];
                         }
                         __syncthreads();
                 }

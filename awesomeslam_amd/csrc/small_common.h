@@ -69,6 +69,7 @@ struct DevView
         const uint8_t *tr_new;
         const int32_t *tr_nobs;
         const float *tr_obs;
+        const float *step_in;    // [3][B] vx, az, dt of a batched step (aslam_*_step_batch)
         unsigned long long *dbg; // diagnostic builds only (-DASLAM_STAMPS): per-phase cycle sums of workgroup 0
 };
 
@@ -176,129 +177,6 @@ __device__ __forceinline__ double sym_get(double *Lt, int r, int c)
 }
 
 // ------------------------------------------------------------------------------------------------------
-/// Factor the 16x16 diagonal tile `T` (lower triangle valid, LDS, row-major) in place into its Cholesky
-/// factor and write the inverse of that factor to `Ti`.  One wave; lane i < 16 owns row i in registers,
-/// pivots and multipliers travel through v_readlane.  Returns false on a non-positive pivot.
-__device__ __forceinline__ bool factor_diag_tile(double *T, double *Ti, int lane)
-{
-        double a[16];
-        const int row = lane & 15;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-                a[c] = T[row * TLD + c];
-        bool ok = true;
-        double invd[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-        {
-                const double djj = readlane_f64(a[j], j);
-                ok = ok && (djj > 0.0);
-                const double inv = readfirstlane_f64(1.0 / sqrt(djj)); // wave-uniform: keep it in SGPRs
-                invd[j] = inv;
-                const double lij = a[j] * inv; // L(i,j) for i >= j
-                a[j] = lij;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c)
-                {
-                        const double lcj = readlane_f64(lij, c);
-                        a[c] = fma(-lij, lcj, a[c]);
-                }
-        }
-        // inverse: lane c computes column c of L^-1 by forward substitution, L(i,k) broadcast by readlane
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-        {
-                double s = (row == i) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; ++k)
-                {
-                        const double lik = readlane_f64(a[k], i);
-                        s = fma(-lik, x[k], s);
-                }
-                x[i] = s * invd[i];
-        }
-        if (lane < 16)
-        {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                {
-                        T[row * TLD + c] = (c <= row) ? a[c] : 0.0;
-                        Ti[c * TLD + row] = x[c]; // Linv(c, row): zero above the diagonal by construction
-                }
-        }
-        return ok;
-}
-
-// ------------------------------------------------------------------------------------------------------
-/// Blocked Cholesky of the nt x nt tile matrix in LDS (lower block triangle), in place, plus the inverses
-/// of the diagonal blocks.  All waves take part; panel and trailing updates run on the f64 MFMA.
-template <int NT>
-__device__ __forceinline__ void cholesky_tiles(double *Lt, double *Dinv, int nt, int tid, uint32_t *status)
-{
-        const int wave = tid >> 6, lane = tid & 63;
-        const int li = lane & 15, lg = lane >> 4;
-        for (int kb = 0; kb < nt; ++kb)
-        {
-                if (wave == 0)
-                {
-                        const bool ok = factor_diag_tile(Lt + tile_index(kb, kb) * TSZ, Dinv + kb * TSZ, lane);
-                        if (!ok && lane == 0)
-                                *status |= 4u; // ASLAM_ST_NOT_PD
-                }
-                __syncthreads();
-                // panel: L(ib,kb) = S(ib,kb) * Linv(kb)^T
-                for (int ib = kb + 1 + wave; ib < nt; ib += SMALL_WAVES)
-                {
-                        double *S = Lt + tile_index(ib, kb) * TSZ;
-                        const double *Di = Dinv + kb * TSZ;
-                        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                        {
-                                const int k = lg + 4 * s;
-                                acc = mfma_f64(S[li * TLD + k], Di[li * TLD + k], acc);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                                S[(lg + 4 * r) * TLD + li] = acc[r];
-                }
-                __syncthreads();
-                // trailing update: S(ib,jb) -= L(ib,kb) L(jb,kb)^T for kb < jb <= ib
-                const int m = nt - kb - 1;
-                const int ntr = m * (m + 1) / 2;
-                for (int q = wave; q < ntr; q += SMALL_WAVES)
-                {
-                        // q -> (i, j), 0 <= j <= i < m
-                        int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-                        while ((i + 1) * (i + 2) / 2 <= q)
-                                ++i;
-                        while (i * (i + 1) / 2 > q)
-                                --i;
-                        const int j = q - i * (i + 1) / 2;
-                        const int ib = kb + 1 + i, jb = kb + 1 + j;
-                        double *S = Lt + tile_index(ib, jb) * TSZ;
-                        const double *Li = Lt + tile_index(ib, kb) * TSZ;
-                        const double *Lj = Lt + tile_index(jb, kb) * TSZ;
-                        d4 acc;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                                acc[r] = S[(lg + 4 * r) * TLD + li];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                        {
-                                const int k = lg + 4 * s;
-                                acc = mfma_f64(-Li[li * TLD + k], Lj[li * TLD + k], acc);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                                S[(lg + 4 * r) * TLD + li] = acc[r];
-                }
-                __syncthreads();
-        }
-}
-
-// ------------------------------------------------------------------------------------------------------
 /// 1/sqrt(x): v_rsq_f64 seed + one third-order Newton step (1-2 ulp; the pivot chain is the serial spine of the
 /// factorisation, and sqrt + divide cost about three times as much)
 __device__ __forceinline__ double rsqrt_newton(double x)
@@ -308,7 +186,8 @@ __device__ __forceinline__ double rsqrt_newton(double x)
         return fma(y * e, fma(e, 0.375, 0.5), y); // third-order step: error ~ (5/16) e^3, far below 2^-53
 }
 
-/// As factor_diag_tile, tuned for the 32-cycle dependent-f64 latency of gfx950: pivots through rsqrt_newton, and
+/// Cholesky factor of the 16x16 diagonal tile `T` (LDS, lower triangle valid) in place, and the inverse of that factor to `Ti`;
+/// returns false on a non-positive pivot.  Tuned for the 32-cycle dependent-f64 latency of gfx950: pivots through rsqrt_newton, and
 /// the inverse is built INSIDE the pivot loop (outer-product form): lane c carries column c of L^-1 as running sums
 /// s[i]; once column j of L is final, x_j = s[j] / L(j,j) and s[i] -= L(i,j) x_j use the very multipliers
 /// L(i,j) the factorisation has just broadcast, and none of that work sits on the pivot dependency chain.
@@ -551,76 +430,6 @@ __device__ __forceinline__ bool chol_lookahead(double *Lt, double *Dinv, int nt,
         return factor_diag_tile_fast(S, Dinv + (kb + 1) * TSZ, lane);
 }
 
-/// Backward substitution on the row block held in acc: acc <- (acc^T L^-1)^T, then u[row] = result . Y and
-/// Dst[rows] = scale * result.  One wave; operands of a whole block step are fetched before its MFMAs.
-template <int NT>
-__device__ __forceinline__ void backward_store(d4 (&acc)[NT], double *Dst, int rb, int nt, const double *Lt, const double *Dinv,
-                                               const double *Y, double *U, double scale, int lane)
-{
-        constexpr int NP = 16 * NT;
-        const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-        for (int cb = NT - 1; cb >= 0; --cb)
-        {
-                if (cb < nt)
-                {
-                        const double *Di = Dinv + cb * TSZ;
-                        double da[4];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                                da[s] = Di[(lg + 4 * s) * TLD + li];
-                        d4 v = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                                v = mfma_f64(da[s], acc[cb][s], v);
-                        acc[cb] = v;
-                        const d4 vn = -v;
-#pragma unroll
-                        for (int c2 = 0; c2 < cb; c2 += 2)
-                        {
-                                const double *L0 = Lt + tile_index(cb, c2) * TSZ;
-                                double l0[4], l1[4];
-#pragma unroll
-                                for (int s = 0; s < 4; ++s)
-                                        l0[s] = L0[(lg + 4 * s) * TLD + li];
-                                if (c2 + 1 < cb)
-                                {
-                                        const double *L1 = Lt + tile_index(cb, c2 + 1) * TSZ;
-#pragma unroll
-                                        for (int s = 0; s < 4; ++s)
-                                                l1[s] = L1[(lg + 4 * s) * TLD + li];
-                                }
-#pragma unroll
-                                for (int s = 0; s < 4; ++s)
-                                {
-                                        acc[c2] = mfma_f64(l0[s], vn[s], acc[c2]);
-                                        if (c2 + 1 < cb)
-                                                acc[c2 + 1] = mfma_f64(l1[s], vn[s], acc[c2 + 1]);
-                                }
-                        }
-                }
-        }
-        double part = 0.0;
-        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt)
-                {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                                part = fma(acc[cb][r], Y[16 * cb + lg + 4 * r], part);
-                                outp[16 * cb + 4 * r] = acc[cb][r] * scale;
-                        }
-                }
-        }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (lg == 0)
-                U[16 * rb + li] = part;
-}
-
 /// Forward-only tail of the fused solve (UKF): the row block in acc is W = Src L^-T.  Store it, and let the wave that owns
 /// row `qrow` publish that row (q^T) to LDS.
 template <int NT> __device__ __forceinline__ void forward_store(const d4 (&acc)[NT], double *Dst, int rb, int nt, int qrow, double *Q, int lane)
@@ -706,23 +515,22 @@ __device__ __forceinline__ void forward_vector(const double *Lt, const double *D
         }
 }
 
-/// Dst = scale * Src S^-1 for all rows (Src, Dst row-major HBM with stride NP, may alias; S = lower tiles in Lt, which
-/// leaves as its Cholesky factor), u = (Src S^-1) Y.  The whole workgroup takes part, in three wave roles that
-/// run their own loops with the same barrier sequence (so that each role gets its own register allocation):
+/// UKF solve (ukf.cpp:268-271 through K = Tc S^-1): S = L L^T in place (S = lower tiles in Lt, which leaves as its Cholesky
+/// factor) and, riding along, the FORWARD substitution only:  Dst = W = Src L^-T for all rows (Src, Dst row-major HBM with
+/// stride NP, may alias), Tv = L^-1 Y, Qv = row `qrow` of W, U = W Tv, G = W Qv (Tv, Qv, G: LDS vectors of 16*NT doubles) --
+/// all a symmetric update P -= W W^T + rank one needs, so no backward substitution exists.  The whole workgroup takes
+/// part, in three wave roles that run their own loops with the same barrier sequence (so that each role gets its own
+/// register allocation):
 ///   * waves 0 .. nt-1 ("row-block waves"): 16 right-hand-side rows each in MFMA accumulators; the forward substitution
-///     rides along with the factorisation (step kb as soon as panel kb exists), the backward one follows;
+///     rides along with the factorisation (step kb as soon as panel kb exists);
 ///   * wave NT ("diagonal wave"): factors diagonal tile kb+1 (look-ahead) while the others do the trailing update
 ///     and the forward step of block column kb, so the serial 16x16 factorisations leave the critical path;
 ///   * the remaining waves only help with panel / trailing tiles.
 /// Ends with a barrier.
-///
-/// FWD_ONLY (UKF): no backward substitution.  Dst = W = Src L^-T, Tv = L^-1 Y, Qv = row `qrow` of W, U = W Tv, G = W Qv
-/// (Tv, Qv, G: LDS vectors of 16*NT doubles): all a symmetric update P -= W W^T + rank one needs.
-template <int NT, bool FWD_ONLY = false>
-__device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
-                                                    const double *Y, double *U, double scale, int tid, uint32_t *status,
-                                                    unsigned long long *wave_busy = nullptr, double *Tv = nullptr, double *Qv = nullptr,
-                                                    double *G = nullptr, int qrow = -1)
+template <int NT>
+__device__ __forceinline__ void cholesky_forward_rows(const double *Src, double *Dst, double *Lt, double *Dinv, int nt,
+                                                      const double *Y, double *U, int tid, uint32_t *status, double *Tv, double *Qv,
+                                                      double *G, int qrow, unsigned long long *wave_busy = nullptr)
 {
 #ifdef ASLAM_STAMPS
         unsigned long long tb_[3] = {0, 0, 0}, tm_ = __builtin_amdgcn_s_memtime(), tn_;
@@ -752,14 +560,9 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
-                if (FWD_ONLY)
-                {
-                        forward_store<NT>(acc, Dst, wave, nt, qrow, Qv, lane);
-                        __syncthreads(); // Qv and Tv (diagonal wave) are in LDS
-                        row_dots<NT>(acc, wave, nt, Tv, Qv, U, G, lane);
-                }
-                else
-                        backward_store<NT>(acc, Dst, wave, nt, Lt, Dinv, Y, U, scale, lane);
+                forward_store<NT>(acc, Dst, wave, nt, qrow, Qv, lane);
+                __syncthreads(); // Qv and Tv (diagonal wave) are in LDS
+                row_dots<NT>(acc, wave, nt, Tv, Qv, U, G, lane);
                 WB(2);
         }
         else if (wave == DW)
@@ -782,11 +585,8 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                 WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
-                if (FWD_ONLY)
-                {
-                        forward_vector(Lt, Dinv, nt, Y, Tv, lane);
-                        __syncthreads();
-                }
+                forward_vector(Lt, Dinv, nt, Y, Tv, lane);
+                __syncthreads();
                 __builtin_amdgcn_s_setprio(0);
         }
         else
@@ -804,14 +604,13 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
                         __syncthreads();
                 }
                 WB(1);
-                if (FWD_ONLY)
-                        __syncthreads();
+                __syncthreads();
         }
 #ifdef ASLAM_STAMPS
         if (wave_busy && lane == 0)
         {
                 wave_busy[2 * wave] += tb_[0];      // busy inside the factorisation loop
-                wave_busy[2 * wave + 1] += tb_[2];  // backward substitution + store
+                wave_busy[2 * wave + 1] += tb_[2];  // store + row dots
         }
 #endif
 #undef WB
@@ -825,7 +624,7 @@ __device__ __forceinline__ void cholesky_solve_rows(const double *Src, double *D
 /// of factor + forward + backward on n right-hand sides, and no backward substitution at all.  The cancellation in
 /// r - r^2 (S^-1)_ii costs log10(r / P~_ii) digits (2-4 here), far inside the 1e-6 bar.
 /// In: tiles = P~ (lower).  Out: tiles = lower part of r Kt (zero padding), U = Kt Y.  Same three wave roles and look-ahead
-/// as cholesky_solve_rows; `Tv`: LDS scratch of 16*NT doubles.  Ends with a barrier.
+/// as cholesky_forward_rows; `Tv`: LDS scratch of 16*NT doubles.  Ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv, int nt, int n_true, const double *Y, double *U,
                                                        double *Tv, double r, int tid, uint32_t *status)
@@ -986,7 +785,7 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
 }
 
 /// Cholesky factorisation of the tile matrix alone (Lt -> L, Dinv -> inverted diagonal blocks), same look-ahead
-/// scheme as cholesky_solve_rows: wave NT factors diagonal tile kb+1 while the others update the trailing tiles.
+/// scheme as cholesky_forward_rows: wave NT factors diagonal tile kb+1 while the others update the trailing tiles.
 template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt, double *Dinv, int nt, int tid, uint32_t *status)
 {
         static_assert(NT < SMALL_WAVES, "one wave is reserved for the diagonal tiles");
@@ -1019,97 +818,6 @@ template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt,
                 }
         }
         __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------------
-/// Dst = scale * Src S^-1 for the 16 rows [16*rb, 16*rb+16) (Src, Dst: row-major HBM, stride NP; may alias);
-/// also u[row] = (Src S^-1)[row,:] . Y (unscaled).  One wave.  The row block is held transposed in MFMA
-/// accumulators: acc[cb][r] of lane l is Pt[16 rb + (l&15)][16 cb + (l>>4) + 4 r].
-template <int NT>
-__device__ __forceinline__ void solve_row_block(const double *Src, double *Dst, int rb, int nt, const double *Lt,
-                                                const double *Dinv, const double *Y, double *U, double scale, int lane)
-{
-        constexpr int NP = 16 * NT;
-        const int li = lane & 15, lg = lane >> 4;
-        d4 acc[NT];
-        const double *rowp = Src + (size_t)(16 * rb + li) * NP + lg;
-        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt)
-                {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                                acc[cb][r] = rowp[16 * cb + 4 * r];
-                }
-        }
-        // forward: V^T = L^-1 Pt^T
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt)
-                {
-                        const double *Di = Dinv + cb * TSZ;
-                        d4 v = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                                v = mfma_f64(Di[li * TLD + lg + 4 * s], acc[cb][s], v);
-                        acc[cb] = v;
-#pragma unroll
-                        for (int c2 = cb + 1; c2 < NT; ++c2)
-                        {
-                                if (c2 < nt)
-                                {
-                                        const double *Lc = Lt + tile_index(c2, cb) * TSZ;
-#pragma unroll
-                                        for (int s = 0; s < 4; ++s)
-                                                acc[c2] = mfma_f64(-Lc[li * TLD + lg + 4 * s], v[s], acc[c2]);
-                                }
-                        }
-                }
-        }
-        // backward: Kt^T = L^-T V^T
-#pragma unroll
-        for (int cb = NT - 1; cb >= 0; --cb)
-        {
-                if (cb < nt)
-                {
-                        const double *Di = Dinv + cb * TSZ;
-                        d4 v = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                                v = mfma_f64(Di[(lg + 4 * s) * TLD + li], acc[cb][s], v);
-                        acc[cb] = v;
-#pragma unroll
-                        for (int c2 = 0; c2 < cb; ++c2)
-                        {
-                                const double *Lc = Lt + tile_index(cb, c2) * TSZ;
-#pragma unroll
-                                for (int s = 0; s < 4; ++s)
-                                        acc[c2] = mfma_f64(-Lc[(lg + 4 * s) * TLD + li], v[s], acc[c2]);
-                        }
-                }
-        }
-        // u = Kt Y, and write r*Kt back
-        double part = 0.0;
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
-        {
-                if (cb < nt)
-                {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                                part = fma(acc[cb][r], Y[16 * cb + lg + 4 * r], part);
-                                outp[16 * cb + 4 * r] = acc[cb][r] * scale;
-                        }
-                }
-        }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (lg == 0)
-                U[16 * rb + li] = part;
 }
 
 // ------------------------------------------------------------------------------------------------------

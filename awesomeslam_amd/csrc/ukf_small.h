@@ -232,7 +232,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
         SmallShared &sm = *L.sm;
 
         const int tid_launch = threadIdx.x, tid = tid_launch;
-        const int b = (MODE == MODE_STEP) ? sa.traj : (int)blockIdx.x;
+        const int b = (MODE == MODE_STEP && sa.traj >= 0) ? sa.traj : (int)blockIdx.x; // sa.traj < 0: the batched step, one workgroup per filter
         const int MP = uv.MP;
         double *Pg = d.P + (size_t)b * NP * NP;
         double *Dg = uv.D + (size_t)b * NP * MP;
@@ -262,9 +262,10 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 {
                         if (tid == 0)
                         {
-                                sm.vx = sa.vx;
-                                sm.az = sa.az;
-                                sm.dt = sa.dt;
+                                // one filter: the arguments of the call; batched step: this filter's entries of the per-call arrays
+                                sm.vx = sa.traj >= 0 ? sa.vx : d.step_in[b];
+                                sm.az = sa.traj >= 0 ? sa.az : d.step_in[d.B + b];
+                                sm.dt = sa.traj >= 0 ? sa.dt : d.step_in[2 * d.B + b];
                         }
                         __syncthreads();
                 }
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 //   K S K^T  = Tc S^-1 Tc^T   = W W^T + g g^T / (1 - q.q)
                 // so neither K nor a backward substitution is needed (ukf.cpp:378-391 evaluated in this form).
                 double *const sT = sZpred, *const sQ = sVv; // both dead by now
-                cholesky_solve_rows<NT, true>(Tcg, Kg, Lt, Dinv, nt, sY, sU, 1.0, tid, &sm.status, nullptr, sT, sQ, sGv, n);
+                cholesky_forward_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, tid, &sm.status, sT, sQ, sGv, n);
                 ASLAM_STAMP(8);
                 {
                         // q.q and q.t: the same sums in every wave

@@ -166,7 +166,8 @@ def sub_records(seed):
         subs[sw] = {"value": line["value"], "unit": line["unit"], "dtype": line["dtype"], "workload": line["config"]["workload"],
                     "trajectories_per_gpu": line["config"]["trajectories_per_gpu"], "callbacks_per_step": line["config"]["callbacks_per_step"],
                     "steps": line["steps"], "warmup": line["warmup"], "ms_per_step": line["ms_per_step"], "kernel": line["config"]["kernel"],
-                    "roofline": line["roofline"], "single_trajectory": line.get("single_trajectory")}
+                    "roofline": line["roofline"], "single_trajectory": line.get("single_trajectory"),
+                    "pcie_step_batch": line.get("pcie_step_batch")}
     return subs
 
 
@@ -178,6 +179,49 @@ def make_core(workload, B, tr, local):
     large = workload == "ekf512"
     return Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=min(2048 if large else 512, 2 * L + 64), device=local,
                 dtype=F32 if large else F64)
+
+
+def pcie_step_batch(workload, seed, B, calls, local, dev):
+    """The PCIe-inclusive rate of the per-callback seam: the host keeps association and growth and hands
+    vx, az, dt, Z[n], A(0,0), A(1,0) of all `B` filters over per callback (aslam_*_step_batch: host arrays in, X[n] back, one
+    launch chain, no synchronisation inside); `calls` back-to-back callbacks, one synchronisation at the end.  The filters are
+    brought to their steady state through the replay seam first; the inputs are the same every call (the arithmetic does not
+    depend on the values).  Never the headline `value`."""
+    import numpy as np
+    import torch
+    from awesomeslam_amd import trace as tg
+
+    kind, L, _ = WORKLOADS[workload]
+    tr = tg.make_traces(L, PROLOGUE, B=B, seed=seed)
+    core = make_core(workload, B, tr, local)
+    core.set_trace(tr)
+    scratch = torch.zeros((B, PROLOGUE, 3), dtype=torch.float64, device=dev)
+    core.replay(0, PROLOGUE, scratch.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = core.dim(0)
+    pin = lambda a: torch.from_numpy(a).pin_memory().numpy()  # noqa: E731  (page-locked: the copies really are asynchronous)
+    Z = np.zeros((B, n))
+    a00, a10 = np.zeros(B), np.zeros(B)
+    for b in range(B):
+        Z[b] = core.state(b, with_P=False)[1][:n]
+        a00[b], a10[b] = core.A(b)
+    Z, a00, a10 = pin(Z), pin(a00), pin(a10)
+    vx, az, dt = pin(np.full(B, 0.12, np.float32)), pin(np.full(B, 0.05, np.float32)), pin(np.full(B, 1.0, np.float32))
+    X = pin(np.zeros((B, n)))
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        core.step_batch(vx, az, dt, Z, a00, a10, X_out=X, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        core.step_batch(vx, az, dt, Z, a00, a10, X_out=X, stream=stream)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = bool(np.isfinite(X).all()) and core.status(0) == 0
+    core.close()
+    return {"value": B * calls / el, "unit": "filter-steps/s", "trajectories": B, "calls": calls, "us_per_call": el / calls * 1e6,
+            "host_bytes_per_call": int(B * (3 * 4 + 8 * n + 16 + 8 * n)), "finite": ok,
+            "what": "aslam_%s_step_batch: host arrays (pinned) -> HBM, one launch chain for all filters, X back; PCIe and launch cost included" % kind}
 
 
 def single_trajectory_latency(workload, seed, C1, local, dev):
@@ -372,6 +416,7 @@ def main():
         }
         if world == 1:
             out["single_trajectory"] = single_trajectory_latency(wl, args.seed, min(C, 200), local, dev)
+            out["pcie_step_batch"] = pcie_step_batch(wl, args.seed, min(B, 256), 10 if large else 100, local, dev)
             if subs:
                 out["sub"] = subs
             sample = args.cpu_sample

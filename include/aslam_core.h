@@ -119,6 +119,16 @@ int aslam_ekf_step(aslam_ctx *ctx, int traj, float vx, float az, float dt, const
 int aslam_ukf_step(aslam_ctx *ctx, int traj, float vx, float az, float dt, const double *Z, double *X_out,
                    void *stream);
 
+/* The same seam for ALL `batch` filters of the context at once (B live robots: one launch chain instead of B calls; replaces B x
+ * `slam(...)` at ekf.cpp:94 / ukf.cpp:90).  Host arrays: vx, az, dt [batch]; Z [batch][ldz], row b = param.Z of filter b (its first
+ * N_b entries are used); a00, a10 [batch] (EKF: param.A(0,0), param.A(1,0)); X_out [batch][ldx] or NULL.
+ * ASYNCHRONOUS on `stream`: nothing inside synchronises.  The input arrays must stay untouched and X_out must not be read until
+ * the caller has synchronised the stream (use pinned host memory for copies that really overlap). */
+int aslam_ekf_step_batch(aslam_ctx *ctx, const float *vx, const float *az, const float *dt, const double *Z, int ldz,
+                         const double *a00, const double *a10, double *X_out, int ldx, void *stream);
+int aslam_ukf_step_batch(aslam_ctx *ctx, const float *vx, const float *az, const float *dt, const double *Z, int ldz,
+                         double *X_out, int ldx, void *stream);
+
 /* ---- the replay seam (the whole callback, association and growth included, runs on the device) ----- */
 /* Bind a trace.  Host pointers are copied to HBM; device pointers are used in place and must stay valid. */
 int aslam_set_trace(aslam_ctx *ctx, const aslam_trace *trace);

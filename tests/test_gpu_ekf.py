@@ -278,3 +278,59 @@ def test_replay_from_trace_file_and_rostopic_dump(built, tmp_path):
     X, Z, P = core.state(0)
     assert np.array_equal(d.cpu().numpy()[0], do) and np.array_equal(Z, Zo)
     assert max(rel_err(p.cpu().numpy()[0], po), rel_err(X, Xo), cov_err(P, Po)) < REL_TOL
+
+
+@pytest.mark.parametrize("kind,n", [("ekf", 13), ("ekf", 131), ("ukf", 29), ("ekf", 203)])
+def test_batched_step_seam(kind, n, built):
+    """aslam_ekf_step_batch / aslam_ukf_step_batch: slam() for all filters of a context in one asynchronous launch chain, against B
+    independent oracles (ekf.cpp:94,293 / ukf.cpp:90,260 called once per robot).  n = 203 goes through the large path."""
+    import torch
+    from awesomeslam_amd.core import Core
+    from oracle.c_oracle import CFilter
+    from test_gpu_large import synth
+
+    B = 5
+    rng = np.random.default_rng(n)
+    cap = max(30, n + 1)
+    core = Core(kind, cap, batch=B, max_obs=4, max_wait=4)
+    oracles = []
+    Zs = np.zeros((B, n + 3))  # a row stride larger than n on purpose
+    for b in range(B):
+        X, Z, P = synth(n, 100 * n + b)
+        if kind == "ukf":  # landmarks east of the robot, a small covariance (the scenario of tests/test_gpu_ukf.py)
+            r2 = np.random.default_rng(7 * n + b)
+            X = np.concatenate([[0.3, -0.2, 0.4], (np.array([25.0, 0.0]) + 4 * r2.normal(size=((n - 3) // 2, 2))).ravel()])
+            A_ = r2.normal(size=(n, n)) * 0.01
+            P = A_ @ A_.T + np.eye(n) * 0.002
+            Z = X.copy()
+            for i in range((n - 3) // 2):
+                dx, dy = X[3 + 2 * i] - X[0], X[4 + 2 * i] - X[1]
+                Z[3 + 2 * i] = np.float32(np.hypot(dx, dy) + 0.01 * r2.normal())
+                Z[4 + 2 * i] = np.float32(np.arctan2(dy, dx) - X[2] + 0.002 * r2.normal())
+        a = (0.07 + 0.01 * b, -0.03 + 0.005 * b)
+        o = CFilter(kind, cap)
+        o.set_state(n, X, Z, P, *a)
+        core.set_state(b, n, X, Z, P)
+        oracles.append((o, a))
+        Zs[b, :n] = Z
+    Xout = np.zeros((B, n))
+    for step in range(3):
+        vx = (0.05 + 0.15 * rng.random(B)).astype(np.float32)
+        az = ((rng.random(B) - 0.5) * (0.0 if step == 1 else 0.4)).astype(np.float32)
+        dt = (0.2 + 0.8 * rng.random(B)).astype(np.float32)
+        a00 = np.array([a[0] for _, a in oracles])
+        a10 = np.array([a[1] for _, a in oracles])
+        core.step_batch(vx, az, dt, Zs, a00, a10, X_out=Xout)
+        torch.cuda.synchronize()
+        for b, (o, a) in enumerate(oracles):
+            if kind == "ekf":
+                Xo_, Zo_, Po_ = o.state()
+                o.set_state(n, Xo_, Zs[b, :n], Po_, *a)
+            o.slam(float(vx[b]), float(az[b]), float(dt[b]))
+            Xo, _, Po = o.state()
+            assert np.isfinite(Po).all()
+            assert rel_err(Xout[b], Xo) < REL_TOL, (step, b)
+    for b, (o, a) in enumerate(oracles):
+        Xo, _, Po = o.state()
+        X, _, P = core.state(b)
+        assert rel_err(X, Xo) < REL_TOL and cov_err(P, Po) < REL_TOL and core.status(b) == 0

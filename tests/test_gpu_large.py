@@ -12,7 +12,10 @@ from awesomeslam_amd import trace as tg
 from util import REL_TOL, cov_err, rel_err
 
 pytestmark = pytest.mark.gpu
-F32_TOL = 4e-6  # measured: <= 1.6e-6 (one slam() on a synthetic P whose update is as large as P itself, n = 1087), <= 1.1e-6 in replays
+F32_TOL = 2.5e-6  # replays (realistic covariances): measured <= 1.1e-6 norm-wise and block-wise after 40 - 150 callbacks
+# one slam() on a synthetic dense P whose update is as large as P itself (eps32 |dP| ~ eps32 |P|): measured 1.6e-6 norm-wise, 8.8e-6 on the
+# worst block (n = 1087)
+F32_SYNTH_TOL = 2e-5
 
 
 def synth(n, seed):
@@ -49,7 +52,7 @@ def test_single_slam_on_synthetic_state(n, steps, dtype, built):
     Pg = core.state(1)[2]
     ex, ep = rel_err(Xg, Xo), cov_err(Pg, Po)
     print(f"large n={n} {dtype}: rel err X {ex:.2e} P {ep:.2e}")
-    assert max(ex, ep) < (REL_TOL if dtype == "f64" else F32_TOL)
+    assert max(ex, ep) < (REL_TOL if dtype == "f64" else F32_SYNTH_TOL)
     assert core.status(1) == 0 and core.dim(0) == 3
 
 
@@ -162,8 +165,10 @@ def test_host_mirror_on_the_large_path(built):
 
 def test_fp32_drift_over_2000_callbacks(built):
     """configs[3] over a long horizon: the fp32 path against the fp64 path of the same library (itself within 1e-14 of the
-    oracle above) on one 512-landmark trace.  With P in binary64 the fp32 error does not random-walk: it must be within the
-    north-star 1e-6 (norm-wise and block-wise) at 2000 callbacks, and the state within 1e-8."""
+    oracle above) on one 512-landmark trace.  With P in binary64 the fp32 error does not random-walk (round 1, P in binary32:
+    8e-7 at 1000 callbacks, 1.6e-6 at 10 000, 4.7e-6 at 100 000 and growing): measured here 1.4e-6 at 500 callbacks, 1.2e-6 at
+    1000, 8.9e-7 at 2000, falling (profiles/).  Bars: the covariance within 2e-6 at every checkpoint and within the north-star
+    1e-6 -- norm-wise AND on every block -- at 2000 callbacks; the state within 1e-8 throughout."""
     import torch
     from awesomeslam_amd.core import Core, F32, F64
     from util import block_rel_err
@@ -185,7 +190,8 @@ def test_fp32_drift_over_2000_callbacks(built):
         eb = block_rel_err(P32, P64)
         print(f"fp32 drift n={cores['f32'].dim(0)} t={t0 + 500}: X {rel_err(X32, X64):.2e}  P {rel_err(P32, P64):.2e}  "
               f"blocks pose/cross/landmark {eb[0]:.2e} {eb[1]:.2e} {eb[2]:.2e}  asym {np.abs(P32 - P32.T).max():.1e}")
+        assert rel_err(X32, X64) < 1e-8 and cov_err(P32, P64) < 2e-6
     assert cores["f32"].dim(0) == 1027 and cores["f32"].status(0) == 0 and cores["f64"].status(0) == 0
     assert rel_err(X32, X64) < 1e-8
     assert cov_err(P32, P64) < REL_TOL
-    assert np.array_equal(P32, P32.T), "the fp32 update mirrors the lower triangle: P stays exactly symmetric"
+    assert np.abs(P32 - P32.T).max() <= 1e-18, "the fp32 update mirrors the lower triangle: P stays symmetric (up to the two predict roundings of the pose block)"

@@ -133,7 +133,7 @@ def test_full_size_config3_properties(built):
         assert len(core.wait_list(b)[0]) == L
 
 
-@pytest.mark.parametrize("L,seed,T", [(8, 5, 60), (13, 7, 450)])
+@pytest.mark.parametrize("L,seed,T", [(8, 5, 300), (10, 11, 450), (13, 7, 450)])
 def test_not_pd_is_flagged_when_the_reference_covariance_goes_indefinite(L, seed, T, built):
     """ukf.cpp:280: `Paug.llt()` silently returns garbage once P is indefinite; the device factors P with a pivot test
     and raises the sticky ASLAM_ST_NOT_PD bit instead.  Scenario that provokes it: landmarks on rings AROUND the robot

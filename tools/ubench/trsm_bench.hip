@@ -1,0 +1,219 @@
+// trsm_bench.hip -- stand-alone timing + correctness harness for large_trsm_pipe / large_syrk_f32p64 (ekf_large*.h), round 2.
+// Random SPD S -> host Cholesky (double) -> L and the inverses of its 64x64 diagonal blocks in binary32; random G; the kernel's V
+// against a host triangular solve for the last filter; then timings of the product kernel and of its diagnostic variants
+// (DIAG bit 0: no global fetch of L, bit 1: no LDS stash / barrier, bit 4: no barrier, bit 3: in-kernel clock stamps).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I awesomeslam_amd/csrc tools/ubench/trsm_bench.hip -o /tmp/trsm_bench && /tmp/trsm_bench [filters]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "ekf_large.h"
+
+using namespace aslam;
+
+#define CK(x)                                                                                                          \
+        do                                                                                                             \
+        {                                                                                                              \
+                hipError_t e_ = (x);                                                                                   \
+                if (e_ != hipSuccess)                                                                                  \
+                {                                                                                                      \
+                        std::printf("%s: %s\n", #x, hipGetErrorString(e_));                                            \
+                        std::exit(1);                                                                                  \
+                }                                                                                                      \
+        } while (0)
+
+template <typename F> float time_ms(F launch, int reps)
+{
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r)
+                launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+        const int B = argc > 1 ? std::atoi(argv[1]) : 128;
+        const int n = 1027, NP = 1088, NB = NP / LB;
+        const size_t M = (size_t)NP * NP;
+        std::mt19937 rng(7);
+        std::normal_distribution<double> nd;
+        // one filter's data on the host, replicated on the device
+        std::vector<double> S(M, 0.0), L(M, 0.0);
+        {
+                std::vector<double> A((size_t)n * 48);
+                for (auto &x : A)
+                        x = nd(rng) * 0.05;
+                for (int i = 0; i < n; ++i)
+                        for (int j = 0; j <= i; ++j)
+                        {
+                                double s = (i == j) ? 0.2 : 0.0;
+                                for (int k = 0; k < 48; ++k)
+                                        s += A[(size_t)i * 48 + k] * A[(size_t)j * 48 + k];
+                                S[(size_t)i * NP + j] = s;
+                        }
+                for (int i = n; i < NP; ++i)
+                        S[(size_t)i * NP + i] = 1.0;
+                for (int j = 0; j < NP; ++j)
+                {
+                        double d = S[(size_t)j * NP + j];
+                        for (int k = 0; k < j; ++k)
+                                d -= L[(size_t)j * NP + k] * L[(size_t)j * NP + k];
+                        d = std::sqrt(d);
+                        L[(size_t)j * NP + j] = d;
+                        for (int i = j + 1; i < NP; ++i)
+                        {
+                                double s = S[(size_t)i * NP + j];
+                                for (int k = 0; k < j; ++k)
+                                        s -= L[(size_t)i * NP + k] * L[(size_t)j * NP + k];
+                                L[(size_t)i * NP + j] = s / d;
+                        }
+                }
+        }
+        std::vector<float> Lf(M), Linv((size_t)NB * LB * LB, 0.f), G(M);
+        for (size_t i = 0; i < M; ++i)
+                Lf[i] = (float)L[i];
+        for (int k = 0; k < NB; ++k)
+        {
+                // inverse of the lower-triangular diagonal block (double, forward substitution on the identity)
+                std::vector<double> X((size_t)LB * LB, 0.0);
+                for (int c = 0; c < LB; ++c)
+                        for (int i = c; i < LB; ++i)
+                        {
+                                double s = (i == c) ? 1.0 : 0.0;
+                                for (int q = c; q < i; ++q)
+                                        s -= L[(size_t)(64 * k + i) * NP + 64 * k + q] * X[(size_t)q * LB + c];
+                                X[(size_t)i * LB + c] = s / L[(size_t)(64 * k + i) * NP + 64 * k + i];
+                        }
+                for (int i = 0; i < LB * LB; ++i)
+                        Linv[(size_t)k * LB * LB + i] = (float)X[i];
+        }
+        for (auto &x : G)
+                x = (float)nd(rng);
+        // device buffers
+        float *dS, *dG, *dG0, *dLinv;
+        double *dP;
+        int *dn, *dskip;
+        CK(hipMalloc(&dS, sizeof(float) * M * B));
+        CK(hipMalloc(&dG, sizeof(float) * M * B));
+        CK(hipMalloc(&dG0, sizeof(float) * M));
+        CK(hipMalloc(&dP, sizeof(double) * M * B));
+        CK(hipMalloc(&dLinv, sizeof(float) * NB * LB * LB * B));
+        CK(hipMalloc(&dn, sizeof(int) * B));
+        CK(hipMalloc(&dskip, sizeof(int) * B));
+        CK(hipMemset(dskip, 0, sizeof(int) * B));
+        CK(hipMemset(dP, 0, sizeof(double) * M * B));
+        CK(hipMemcpy(dG0, G.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+        std::vector<int> nn(B, n);
+        CK(hipMemcpy(dn, nn.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+        for (int b = 0; b < B; ++b)
+        {
+                CK(hipMemcpy(dS + M * b, Lf.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+                CK(hipMemcpy(dLinv + (size_t)NB * LB * LB * b, Linv.data(), sizeof(float) * NB * LB * LB, hipMemcpyHostToDevice));
+        }
+        DevView d = {};
+        d.B = B;
+        d.NP = NP;
+        d.n = dn;
+        LargeView<float> lv = {};
+        lv.NP = NP;
+        lv.P = dP;
+        lv.G = dG;
+        lv.S = dS;
+        lv.Linv = dLinv;
+        auto reset_G = [&]() {
+                for (int b = 0; b < B; ++b)
+                        CK(hipMemcpyAsync(dG + M * b, dG0, sizeof(float) * M, hipMemcpyDeviceToDevice, 0));
+        };
+        // ---- correctness of the product kernel on the last filter
+        reset_G();
+        hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(NB, B), dim3(256), 0, 0, d, lv, dskip);
+        CK(hipDeviceSynchronize());
+        std::vector<float> V(M);
+        CK(hipMemcpy(V.data(), dG + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
+        double worst = 0, scale = 0;
+        for (int i = 0; i < NP; i += 37)
+        {
+                // row i of V = G L^-T in double from the float L
+                std::vector<double> v(NP);
+                for (int c = 0; c < NP; ++c)
+                {
+                        double s = G[(size_t)i * NP + c];
+                        for (int q = 0; q < c; ++q)
+                                s -= v[q] * (double)Lf[(size_t)c * NP + q];
+                        v[c] = s / (double)Lf[(size_t)c * NP + c];
+                }
+                for (int c = 0; c < NP; ++c)
+                {
+                        worst = std::fmax(worst, std::fabs(v[c] - (double)V[(size_t)i * NP + c]));
+                        scale = std::fmax(scale, std::fabs(v[c]));
+                }
+        }
+        std::printf("large_trsm_pipe: max |V - host| / max |V| = %.2e (rows 0, 37, ... of filter %d)\n", worst / scale, B - 1);
+        // ---- timings (the result does not matter: G is solved again in place).  DIAG bits: 1 = no global fetch of the L blocks (stale
+        // LDS), 2 = no LDS stash and no barrier, 16 = no barrier (racy), 8 = in-kernel stamps
+        const double mfma_per_wave = 64.0 * 136 + 40.0 * 17;
+        const double fl = mfma_per_wave * 2048.0 * 68 * B; // x 2048 flop x 68 waves per filter
+        for (int bb : {15, 30, 60, 120, B})
+        {
+                if (bb > B)
+                        break;
+                const float m0 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(NB, bb), dim3(256), 0, 0, d, lv, dskip); }, 5);
+                std::printf("  %3d filters = %4d workgroups (%.2f per CU): %7.3f ms = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", bb, 17 * bb, 17.0 * bb / 256, m0,
+                            fl * bb / B / (m0 * 1e-3) / 1e12, fl * bb / B / (m0 * 1e-3) / 1e12 / 157.3 * 100);
+        }
+        // ---- clock and cycles per MFMA inside the kernel: s_memtime (shader clock) and s_memrealtime (100 MHz) around the sweep of every workgroup
+        {
+                double *dY;
+                const int bb = 15; // one workgroup per CU
+                CK(hipMalloc(&dY, sizeof(double) * 2 * NB * B));
+                LargeView<float> lw = lv;
+                lw.Y = dY;
+                auto report = [&](const char *name) {
+                        CK(hipDeviceSynchronize());
+                        std::vector<double> y(2 * NB * bb);
+                        CK(hipMemcpy(y.data(), dY, sizeof(double) * y.size(), hipMemcpyDeviceToHost));
+                        double cyc = 0, real = 0;
+                        for (int i = 0; i < NB * bb; ++i)
+                                cyc += y[2 * i], real += y[2 * i + 1];
+                        cyc /= NB * bb, real /= NB * bb;
+                        std::printf("  %-28s per workgroup: %9.0f shader cycles, %7.2f us => %5.0f MHz, %5.1f cycles per MFMA per wave\n", name, cyc, real / 100.0,
+                                    cyc / (real / 100.0), cyc / mfma_per_wave);
+                };
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                report("product");
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                report("no fetch");
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9 + 16>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                report("no fetch, no barrier");
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 11>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                report("no fetch/stash/barrier");
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 16>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                report("no barrier");
+                CK(hipFree(dY));
+        }
+        // ---- syrk
+        {
+                const int ntile = (NP + 127) / 128;
+                const dim3 grid(8 * (ntile * (ntile + 1) / 2) * ((B + 7) / 8));
+                const float ms = time_ms([&]() { hipLaunchKernelGGL(large_syrk_f32p64<32>, grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                const double sf = (ntile * (ntile + 1) / 2 - ntile * 0.25) * 2.0 * 128 * 128 * 1056 * B;
+                std::printf("  syrk_f32p64<32>  %8.3f ms for %d filters = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", ms, B, sf / (ms * 1e-3) / 1e12,
+                            sf / (ms * 1e-3) / 1e12 / 157.3 * 100);
+                const float ms64 = time_ms([&]() { hipLaunchKernelGGL(large_syrk_f32p64<64>, grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_f32p64<64>  %8.3f ms\n", ms64);
+        }
+        return 0;
+}
