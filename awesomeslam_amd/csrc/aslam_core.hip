@@ -71,6 +71,11 @@ struct aslam_ctx
         // the others
         static constexpr int LARGE_GROUPS = 8; // capacity; the default below was chosen by measurement (profiles/)
         int large_groups = 4;                  // ASLAM_LARGE_GROUPS=1..8 overrides (1 = a single stream, for per-kernel profiling)
+        // binary32 mode: Cholesky of S as ONE launch with a filter per workgroup (large_chol_resident) when the batch can fill the
+        // chip that way, as 33 multi-workgroup launches (diagonal block + panel per block column) for few filters.
+        // ASLAM_CHOL_RESIDENT=0/1 forces one form.
+        int chol_resident = -1;
+        static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
         hipStream_t aux[LARGE_GROUPS - 1] = {};
         hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
 };
@@ -300,6 +305,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 g.skip += b;
                 return g;
         };
+        const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : Bz >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
         auto chain = [&](const Group &g, int s) {
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
@@ -310,12 +316,15 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 {
                         // binary32: Cholesky of S alone (17 x {diagonal block, panel of S}), then V = G L^-T with the solved columns
                         // resident in registers (one launch), then P -= V V^T into the fp64 covariance
-                        for (int k = 0; k < NB; ++k)
-                        {
-                                hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
-                                if (k + 1 < NB)
-                                        hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
-                        }
+                        if (resident)
+                                hipLaunchKernelGGL(large_chol_resident<LARGE_NB_MAX>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                        else
+                                for (int k = 0; k < NB; ++k)
+                                {
+                                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                                        if (k + 1 < NB)
+                                                hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
+                                }
                         hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(NB, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                         hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
@@ -489,6 +498,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                 A_(dev_alloc(c, &c->skipped, B, c->owned));
                 if (const char *e = std::getenv("ASLAM_LARGE_GROUPS"))
                         c->large_groups = std::max(1, std::min((int)aslam_ctx::LARGE_GROUPS, std::atoi(e)));
+                if (const char *e = std::getenv("ASLAM_CHOL_RESIDENT"))
+                        c->chol_resident = std::atoi(e) != 0;
                 for (hipStream_t &q : c->aux)
                         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
                                 rc = ASLAM_ERR_HIP;

@@ -1059,3 +1059,4 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
 } // namespace aslam
 
 #include "ekf_large_trsm.h"
+#include "ekf_large_chol.h"

@@ -1,0 +1,203 @@
+// ekf_large_chol.h -- S = L L^T for the large-state EKF in binary32 (the factor behind K = P H^T S^-1, ekf.cpp:301), one workgroup
+// per filter, the whole factorisation in ONE launch.
+//
+// Row block I of L obeys the very recurrence large_trsm_pipe runs on the rows of G:
+//      L(I, k) = ( S(I, k) - sum_{j<k} L(I, j) L(k, j)^T ) Linv_k^T            k < I
+//      L(I, I) L(I, I)^T = S(I, I) - sum_{j<I} L(I, j) L(I, j)^T               (a 64x64 Cholesky)
+// so the factorisation is 17 such strip sweeps, block row after block row, each needing all earlier block rows complete.  The
+// round-2 chain before this kernel spent 33 launches on it (17 x {diagonal block, left-looking panel}): 1.6 ms per 128 filters, with
+// grids that shrink to one workgroup per filter -- the serial spine of every stream group.  Here a filter stays on one CU: no
+// inter-workgroup dependency exists, the filters of a batch are the parallelism (256 filters = one workgroup on every CU), and the
+// 64x64 diagonal factorisations run in the same workgroup between two sweeps.  Every block of L is re-read once per later block row
+// (13 MB per filter from HBM, against 38 MB for the old panel), at the rate large_trsm_pipe already streams them.
+//
+// The diagonal block: C = S(I,I) - sum (binary32, from the MFMA accumulators) goes to LDS as binary64 16x16 tiles; four waves factor it
+// with the fp64 tile kernels of the small path (factor_diag_tile_fast + fp64 MFMA panel / trailing updates), build L(I,I)^-1 tile by
+// tile (Linv_ij = -Linv_ii sum_k L_ik Linv_kj), and write both back in binary32.
+#pragma once
+
+namespace aslam
+{
+namespace chol64
+{
+// LDS tile map (binary64 tiles of TSZ doubles, rows of TLD): L (lower 4x4: 10 tiles) | inverses of the diagonal tiles (4) |
+// R(i,j) = Linv(i,j)^T (lower: 10) | one transposed product per wave (4)
+constexpr int TILES = 28;
+__device__ __forceinline__ int lower(int i, int j) { return i * (i + 1) / 2 + j; }
+__device__ __forceinline__ double *Lt(double *t, int i, int j) { return t + lower(i, j) * TSZ; }
+__device__ __forceinline__ double *Ti(double *t, int k) { return t + (10 + k) * TSZ; }
+__device__ __forceinline__ double *Rt(double *t, int i, int j) { return t + (14 + lower(i, j)) * TSZ; }
+__device__ __forceinline__ double *Wt(double *t, int w) { return t + (24 + w) * TSZ; }
+
+/// acc += X Y^T for two row-major 16x16 tiles; acc[r] of lane (li, lg) = element (lg + 4 r, li)
+__device__ __forceinline__ d4 xyt(const double *X, const double *Y, d4 acc, double sign, int li, int lg)
+{
+        double xa[4], yb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+                xa[s] = sign * X[li * TLD + lg + 4 * s];
+                yb[s] = Y[li * TLD + lg + 4 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+                acc = mfma_f64(xa[s], yb[s], acc);
+        return acc;
+}
+
+/// In: the lower 4x4 tiles of a symmetric positive definite 64x64 matrix in Lt.  Out: its Cholesky factor in Lt (zeros above the
+/// diagonal of the diagonal tiles) and R = (L^-1)^T tiles.  256 threads; starts and ends with a barrier.  Returns false (on wave 0)
+/// on a non-positive pivot.
+__device__ __forceinline__ bool factor_and_invert(double *t, int tid)
+{
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        bool ok = true;
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < 4; ++kb)
+        {
+                if (wave == 0)
+                        ok = factor_diag_tile_fast(Lt(t, kb, kb), Ti(t, kb), lane) && ok;
+                __syncthreads();
+                // panel: L(ib, kb) = S(ib, kb) Linv_kb^T, one tile per wave; wave 3 (never has one) transposes Linv_kb into R(kb, kb)
+                const int ib = kb + 1 + wave;
+                if (ib < 4)
+                {
+                        double *S = Lt(t, ib, kb);
+                        const d4 p = xyt(S, Ti(t, kb), (d4){0.0, 0.0, 0.0, 0.0}, 1.0, li, lg);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                S[(lg + 4 * r) * TLD + li] = p[r];
+                }
+                if (wave == 3)
+                {
+                        const double *src = Ti(t, kb);
+                        double *dst = Rt(t, kb, kb);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                                const int e = lane + 64 * q;
+                                dst[(e >> 4) * TLD + (e & 15)] = src[(e & 15) * TLD + (e >> 4)];
+                        }
+                }
+                __syncthreads();
+                // trailing update: S(ib, jb) -= L(ib, kb) L(jb, kb)^T for kb < jb <= ib: up to six tiles over four waves
+                const int m = 3 - kb, cnt = m * (m + 1) / 2;
+                for (int q = wave; q < cnt; q += 4)
+                {
+                        const int i = (q >= 3) ? 2 : (q >= 1) ? 1 : 0, j = q - i * (i + 1) / 2;
+                        double *S = Lt(t, kb + 1 + i, kb + 1 + j);
+                        d4 acc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                acc[r] = S[(lg + 4 * r) * TLD + li];
+                        acc = xyt(Lt(t, kb + 1 + i, kb), Lt(t, kb + 1 + j, kb), acc, -1.0, li, lg);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                S[(lg + 4 * r) * TLD + li] = acc[r];
+                }
+                __syncthreads();
+        }
+        // the off-diagonal tiles of the inverse, diagonal by diagonal:  W = sum_{k=j}^{i-1} L(i,k) Linv(k,j),  Linv(i,j) = -Linv(i,i) W;
+        // stored transposed: R(i,j) = Linv(i,j)^T = -W^T Linv(i,i)^T
+#pragma unroll 1
+        for (int dgl = 1; dgl < 4; ++dgl)
+        {
+                const int j = wave, i = j + dgl;
+                if (i < 4)
+                {
+                        d4 w = {0.0, 0.0, 0.0, 0.0};
+                        for (int k = j; k < i; ++k)
+                                w = xyt(Lt(t, i, k), Rt(t, k, j), w, 1.0, li, lg); // L(i,k) (R(k,j))^T = L(i,k) Linv(k,j)
+                        double *W = Wt(t, wave);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                W[li * TLD + lg + 4 * r] = w[r]; // transposed
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier(); // the same wave reads W back through LDS
+                        const d4 x = xyt(W, Ti(t, i), (d4){0.0, 0.0, 0.0, 0.0}, -1.0, li, lg); // -W^T Linv(i,i)^T
+                        double *R = Rt(t, i, j);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                R[(lg + 4 * r) * TLD + li] = x[r];
+                }
+                __syncthreads();
+        }
+        return ok;
+}
+} // namespace chol64
+
+/// grid (B), 256 threads: the Cholesky factor of S (lower block triangle, in place) and the inverses of its diagonal blocks (lv.Linv)
+/// for filter blockIdx.x.  Status bit 4 (ASLAM_ST_NOT_PD) on a non-positive pivot, as large_potrf_inv.
+template <int NBMAX>
+__global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeView<float> lv, const int *skipped)
+{
+        static_assert(NBMAX == 17, "trsm_sweep lists 17 block columns");
+        constexpr int PIPE_BYTES = 3 * LB * TRSM_LDT * (int)sizeof(float), TILE_BYTES = chol64::TILES * TSZ * (int)sizeof(double);
+        // the block pipeline of a sweep and the tiles of the diagonal factorisation never live at the same time
+        __shared__ __attribute__((aligned(16))) unsigned char raw[PIPE_BYTES > TILE_BYTES ? PIPE_BYTES : TILE_BYTES];
+        float *pipe = reinterpret_cast<float *>(raw);
+        double *tiles = reinterpret_cast<double *>(raw);
+        const int b = blockIdx.x;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int a_off = li * TRSM_LDT + 4 * lg;
+        float *Sb = lv.S + (size_t)b * NP * NP;
+        float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
+        asm volatile("" ::: "a0", "a255"); // the strip (ekf_large_trsm.h)
+        bool ok = true;
+#pragma unroll 1
+        for (int I = 0; I < nb; ++I)
+        {
+                float *Srow = Sb + ((size_t)LB * I + 16 * wave + li) * NP + 4 * lg; // this lane's row of block row I (+ 4 lg)
+                TrsmSeq seq(Sb, Linv, 0, I, NP, tid);
+                const TrsmSeq seq_diag(Sb, Linv, I, I + 1, NP, tid); // the history blocks of the diagonal block: L(I, 0 .. I-1), this sweep's own output
+                TrsmPipe pp = {pipe, pipe + LB * TRSM_LDT, pipe + 2 * LB * TRSM_LDT};
+                f4 c[4];
+                trsm_sweep<0, true>(c, Srow, I, seq, seq_diag, pp, a_off, tid);
+                __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
+                // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                {
+                        if (t <= wave)
+                        {
+                                double *T = chol64::Lt(tiles, wave, t) + li * TLD + 4 * lg;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        T[r] = (double)c[t][r];
+                        }
+                }
+                ok = chol64::factor_and_invert(tiles, tid) && ok;
+                // L(I,I) -> S (zeros above the diagonal), Linv_I -> lv.Linv: thread = row r, 16-column segment q
+                {
+                        const int r = tid >> 2, q = tid & 3, ti = r >> 4, a = r & 15;
+                        float *ls = Sb + ((size_t)LB * I + r) * NP + (size_t)LB * I + 16 * q;
+                        float *li_out = Linv + (size_t)I * LB * LB + r * LB + 16 * q;
+                        const double *Ltile = chol64::Lt(tiles, ti, min(q, ti)) + a * TLD;
+                        const double *Rtile = chol64::Rt(tiles, ti, min(q, ti)) + a;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                        {
+                                f4 lo, io;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                {
+                                        lo[e] = (q <= ti) ? (float)Ltile[4 * v + e] : 0.f;
+                                        io[e] = (q <= ti) ? (float)Rtile[(4 * v + e) * TLD] : 0.f; // Linv(a, b) = R(b, a)
+                                }
+                                *reinterpret_cast<f4 *>(ls + 4 * v) = lo;
+                                *reinterpret_cast<f4 *>(li_out + 4 * v) = io;
+                        }
+                }
+                // the next block row reads them back through the block pipeline
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+        }
+        if (!ok && tid == 0)
+                atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
+}
+} // namespace aslam

@@ -147,26 +147,32 @@ template <int K> __device__ __forceinline__ void trsm_keep(const f4 (&x)[4])
 // is written while block i is multiplied, so block i + 1 is already visible and its first two fragment sets are read behind the last
 // MFMAs of block i; the barrier sits 16 MFMAs behind the LDS traffic it waits for.
 
-/// branch-free cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ...  (clamped at the end: the last
-/// blocks are fetched again, which is harmless)
+/// cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ...  up to Linv_{nb-1} (which is then fetched
+/// again and again: the pipeline runs two blocks past the end).  Scalar state only, advanced with selects: a taken branch per
+/// block costs a single-wave-per-SIMD kernel more than the arithmetic.
 struct TrsmSeq
 {
         int k, j, nb, NP;
-        const float *Sb, *Linv;
-        int r0, c4; // this thread's 16 bytes of a block: rows r0 + 16 q, columns c4 .. c4 + 3
+        const float *rowp, *linvp; // L(k, 0) and Linv_k
+        int r0, c4;                // this thread's 16 bytes of a block: rows r0 + 16 q, columns c4 .. c4 + 3
+        __device__ __forceinline__ TrsmSeq(const float *Sb, const float *Linv, int k0, int nb_, int NP_, int tid)
+            : k(k0), j(0), nb(nb_), NP(NP_), rowp(Sb + (size_t)(LB * k0) * NP_), linvp(Linv + (size_t)k0 * LB * LB), r0(tid >> 4), c4((tid & 15) * 4)
+        {
+        }
         __device__ __forceinline__ void fetch(f4 (&pf)[4])
         {
-                const int kk = min(k, nb - 1);
-                const bool hist = j < kk;
-                // wave-uniform row bases (scalar registers) + one 32-bit lane offset: no 64-bit vector arithmetic per block
-                const float *blk = hist ? Sb + (size_t)(LB * kk) * NP + LB * j : Linv + (size_t)kk * LB * LB;
+                const bool hist = j < k;
+                const float *blk = hist ? rowp + LB * j : linvp;
                 const int ld = hist ? NP : LB;
                 const unsigned off = (unsigned)(r0 * ld + c4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                         pf[q] = *reinterpret_cast<const f4 *>(blk + (size_t)(16 * q * ld) + off);
-                j = hist ? j + 1 : 0;
-                k = hist ? k : k + 1;
+                const bool adv = !hist && k + 1 < nb;
+                j = hist ? j + 1 : (adv ? 0 : j);
+                k += adv ? 1 : 0;
+                rowp += adv ? (size_t)LB * NP : 0;
+                linvp += adv ? LB * LB : 0;
         }
 };
 
@@ -221,55 +227,59 @@ __device__ __forceinline__ void trsm_chain_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&a1
         }
 }
 
-/// grid (NP / 64, B), 256 threads; wave w of workgroup x owns rows [64 x + 16 w, +16) of G.  In place: G -> V.
-template <int NBMAX, int DIAG = 0>
-__global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<float> lv, const int *skipped)
+/// (re)start of the block pipeline at the block `seq` points at: blocks i, i + 1 -> LDS, block i + 2 -> registers, the first two fragment
+/// sets of block i -> a0 / a1.  The caller guarantees that no wave still reads the three buffers (a barrier since the last read).
+__device__ __forceinline__ void trsm_pipe_start(f4 (&pf)[4], f4 (&a0)[4], f4 (&a1)[4], TrsmPipe &pp, TrsmSeq &seq, int a_off, int tid)
 {
-        static_assert(NBMAX == 17, "the switch below lists 17 block columns");
-        __shared__ __attribute__((aligned(16))) float lds[3][LB * TRSM_LDT];
-        const int b = blockIdx.y;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        const int nb = large_blocks(n);
-        if ((int)blockIdx.x >= nb)
-                return;
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * blockIdx.x + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
-        const int a_off = li * TRSM_LDT + 4 * lg;
-        asm volatile("" ::: "a0", "a255"); // the strip (see above)
-        unsigned long long t0_ = 0, r0_ = 0;
-        if constexpr (DIAG & 8)
-        {
-                t0_ = __builtin_amdgcn_s_memtime();
-                r0_ = __builtin_amdgcn_s_memrealtime();
-        }
-        TrsmSeq seq = {0, 0, nb, NP, lv.S + (size_t)b * NP * NP, lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB, tid >> 4, (tid & 15) * 4};
-        TrsmPipe pp = {lds[0], lds[1], lds[2]};
-        f4 pf[4], a0[4], a1[4], c[4], g0[4];
         seq.fetch(pf);
         trsm_stash(pp.cur, pf, tid);
         seq.fetch(pf);
         trsm_stash(pp.nxt, pf, tid);
-        seq.fetch(pf); // block 2: written to LDS during block 0
+        seq.fetch(pf); // block i + 2: written to LDS during block i
+        __syncthreads();
+        trsm_frags(a0, pp.cur, a_off, 0);
+        trsm_frags(a1, pp.cur, a_off, 1);
+}
+
+/// The sweep of one 16-row strip per wave over block columns 0 .. nbk - 1:  X(:, k) = (G(:, k) - sum_{j<k} X(:, j) L(k, j)^T) Linv_k^T,
+/// written over G and kept in the strip.  `Grow`: this lane's row (+ 4 lg).
+/// CHOL (large_chol_resident: the rows are block row nbk of S itself): block column nbk follows, closed differently -- its history
+/// blocks are L(nbk, j) = the X(:, j) this very sweep has just stored, so the pipeline is drained and restarted in front of them, and
+/// the sweep returns  c = S(nbk, nbk) - sum_j X(:, j) X(:, j)^T  (this wave's 16 rows: c[t][r] = column 16 t + 4 lg + r of row li)
+/// for the caller to factor.  `seq` walks Linv_0; L(1,0), Linv_1; ... (nb = nbk), `seq_diag` (CHOL only) starts at L(nbk, 0).
+template <int DIAG, bool CHOL>
+__device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, TrsmSeq &seq, const TrsmSeq &seq_diag, TrsmPipe &pp, int a_off, int tid)
+{
+        f4 pf[4], a0[4], a1[4], g0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
         {
                 c[t] = (f4){0.f, 0.f, 0.f, 0.f};
                 g0[t] = *reinterpret_cast<const f4 *>(Grow + 16 * t); // G[row][16 t + 4 lg .. +3]
         }
-        __syncthreads();
-        trsm_frags(a0, pp.cur, a_off, 0);
-        trsm_frags(a1, pp.cur, a_off, 1);
+        if (!CHOL || nbk > 0)
+                trsm_pipe_start(pf, a0, a1, pp, seq, a_off, tid);
+        const int klast = CHOL ? nbk : nbk - 1;
 #pragma unroll 1
-        for (int k = 0; k < nb; ++k)
+        for (int k = 0; k <= klast; ++k)
         {
+                if (CHOL && k == nbk)
+                {
+                        // the history blocks of the diagonal block column are this workgroup's own output: every store has to have left
+                        // the CU's memory pipeline, and every wave has to be done with the LDS buffers, before the pipeline restarts
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        seq = seq_diag; // L(nbk, 0), ..., L(nbk, nbk - 1)
+                        trsm_pipe_start(pf, a0, a1, pp, seq, a_off, tid);
+                }
                 trsm_chain_pipe<0, DIAG>(c, a0, a1, pf, k, pp, seq, a_off, tid);
                 // ---- the closing block of column k: C = G - history, X = Linv_k C (a0 = tiles (t, 0), a1 = tiles (t, 1) of Linv_k)
                 asm volatile("s_nop 15" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); // MFMA result -> VALU read
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                         c[t] = g0[t] - c[t];
+                if (CHOL && k == nbk)
+                        break;
                 asm volatile("s_nop 4" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); // VALU result -> MFMA operand
                 f4 x[4];
 #pragma unroll
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
 #undef ASLAM_TRSM_KEEP
                 }
                 // next block column: fresh accumulators, its slice of G (consumed k + 1 blocks from now)
-                const int kn = min(k + 1, nb - 1);
+                const int kn = min(k + 1, klast);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                 {
@@ -334,6 +344,35 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
                 }
                 pp.rotate();
         }
+}
+
+/// V = G L^-T.  grid (NP / 64, B), 256 threads; wave w of workgroup x owns rows [64 x + 16 w, +16) of G.  In place: G -> V.
+template <int NBMAX, int DIAG = 0>
+__global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<float> lv, const int *skipped)
+{
+        static_assert(NBMAX == 17, "trsm_sweep lists 17 block columns");
+        __shared__ __attribute__((aligned(16))) float lds[3][LB * TRSM_LDT];
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        if ((int)blockIdx.x >= nb)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * blockIdx.x + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
+        const int a_off = li * TRSM_LDT + 4 * lg;
+        asm volatile("" ::: "a0", "a255"); // the strip (see above)
+        unsigned long long t0_ = 0, r0_ = 0;
+        if constexpr (DIAG & 8)
+        {
+                t0_ = __builtin_amdgcn_s_memtime();
+                r0_ = __builtin_amdgcn_s_memrealtime();
+        }
+        TrsmSeq seq(lv.S + (size_t)b * NP * NP, lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB, 0, nb, NP, tid);
+        TrsmPipe pp = {lds[0], lds[1], lds[2]};
+        f4 c[4];
+        trsm_sweep<DIAG, false>(c, Grow, nb, seq, seq, pp, a_off, tid);
         if constexpr (DIAG & 8)
         {
                 if (tid == 0)

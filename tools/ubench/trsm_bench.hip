@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -174,6 +175,12 @@ int main(int argc, char **argv)
                 std::printf("  %3d filters = %4d workgroups (%.2f per CU): %7.3f ms = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", bb, 17 * bb, 17.0 * bb / 256, m0,
                             fl * bb / B / (m0 * 1e-3) / 1e12, fl * bb / B / (m0 * 1e-3) / 1e12 / 157.3 * 100);
         }
+        // ---- one workgroup per FILTER (grid (1, B)): every workgroup streams its own copy of L, nothing is shared through the L2 -- the access
+        // pattern of a Cholesky that keeps one filter on one CU
+        {
+                const float m1 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(1, B), dim3(256), 0, 0, d, lv, dskip); }, 5);
+                std::printf("  one workgroup per filter, %d filters: %7.3f ms (a workgroup's sweep alone on its CU: ~0.19 ms when L is shared through the L2)\n", B, m1);
+        }
         // ---- clock and cycles per MFMA inside the kernel: s_memtime (shader clock) and s_memrealtime (100 MHz) around the sweep of every workgroup
         {
                 double *dY;
@@ -203,6 +210,72 @@ int main(int argc, char **argv)
                 hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 16>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
                 report("no barrier");
                 CK(hipFree(dY));
+        }
+        // ---- large_chol_resident: S (binary32 copy of the SPD matrix) -> L, Linv against the host factor; then its time
+        {
+                std::vector<float> Sf(M);
+                for (int i = 0; i < NP; ++i)
+                        for (int j = 0; j < NP; ++j)
+                                Sf[(size_t)i * NP + j] = (float)(i >= j ? S[(size_t)i * NP + j] : S[(size_t)j * NP + i]);
+                uint32_t *dstatus;
+                CK(hipMalloc(&dstatus, sizeof(uint32_t) * B));
+                CK(hipMemset(dstatus, 0, sizeof(uint32_t) * B));
+                DevView dc = d;
+                dc.status = dstatus;
+                auto reset_S = [&]() {
+                        for (int b = 0; b < B; ++b)
+                                CK(hipMemcpyAsync(dS + M * b, Sf.data(), sizeof(float) * M, hipMemcpyHostToDevice, 0));
+                        CK(hipMemsetAsync(dLinv, 0xff, sizeof(float) * NB * LB * LB * B, 0)); // NaNs: nothing may be read before it is written
+                };
+                reset_S();
+                hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lv, dskip);
+                CK(hipDeviceSynchronize());
+                std::vector<float> Lg(M), Lig((size_t)NB * LB * LB);
+                std::vector<uint32_t> st(B);
+                CK(hipMemcpy(Lg.data(), dS + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(Lig.data(), dLinv + (size_t)NB * LB * LB * (B - 1), sizeof(float) * Lig.size(), hipMemcpyDeviceToHost));
+                CK(hipMemcpy(st.data(), dstatus, sizeof(uint32_t) * B, hipMemcpyDeviceToHost));
+                double eL = 0, sL = 0, eI = 0, sI = 0;
+                for (int i = 0; i < NP; ++i)
+                        for (int j = 0; j <= i; ++j)
+                        {
+                                eL = std::fmax(eL, std::fabs((double)Lg[(size_t)i * NP + j] - L[(size_t)i * NP + j]));
+                                sL = std::fmax(sL, std::fabs(L[(size_t)i * NP + j]));
+                        }
+                for (size_t i = 0; i < Lig.size(); ++i)
+                {
+                        eI = std::fmax(eI, std::fabs((double)Lig[i] - (double)Linv[i]));
+                        sI = std::fmax(sI, std::fabs((double)Linv[i]));
+                }
+                uint32_t anyst = 0;
+                for (uint32_t x : st)
+                        anyst |= x;
+                std::printf("large_chol_resident: max |L - host| / max |L| = %.2e, max |Linv - host| / max |Linv| = %.2e, status bits %u (filter %d)\n", eL / sL,
+                            eI / sI, anyst, B - 1);
+                for (int bb : {15, 64, 128, B})
+                {
+                        if (bb > B)
+                                break;
+                        reset_S();
+                        CK(hipDeviceSynchronize());
+                        hipEvent_t e0, e1;
+                        CK(hipEventCreate(&e0));
+                        CK(hipEventCreate(&e1));
+                        CK(hipEventRecord(e0));
+                        hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(bb), dim3(256), 0, 0, dc, lv, dskip);
+                        CK(hipEventRecord(e1));
+                        CK(hipEventSynchronize(e1));
+                        float ms = 0;
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        std::printf("  chol_resident %3d filters: %7.3f ms\n", bb, ms);
+                }
+                // restore the factor for the kernels timed below
+                for (int b = 0; b < B; ++b)
+                {
+                        CK(hipMemcpy(dS + M * b, Lf.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+                        CK(hipMemcpy(dLinv + (size_t)NB * LB * LB * b, Linv.data(), sizeof(float) * NB * LB * LB, hipMemcpyHostToDevice));
+                }
+                CK(hipFree(dstatus));
         }
         // ---- syrk
         {
