@@ -325,7 +325,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                         if (k + 1 < NB)
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
-                        hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(NB, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                        hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 else

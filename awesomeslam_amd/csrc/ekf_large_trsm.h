@@ -346,21 +346,25 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, Trs
         }
 }
 
-/// V = G L^-T.  grid (NP / 64, B), 256 threads; wave w of workgroup x owns rows [64 x + 16 w, +16) of G.  In place: G -> V.
+/// V = G L^-T.  grid (8 * ceil(B / 8) * NP / 64), 256 threads; wave w of a workgroup owns 16 rows of G.  In place: G -> V.
+/// The 17 workgroups of a filter stream the same blocks of L: they are dealt to ONE XCD (workgroup i runs on XCD i % 8), next to each other
+/// in its dispatch order, so that a block comes from HBM once and from that XCD's L2 sixteen times (PMC: 23.6 -> MB per filter and callback).
 template <int NBMAX, int DIAG = 0>
-__global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<float> lv, const int *skipped)
+__global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
 {
         static_assert(NBMAX == 17, "trsm_sweep lists 17 block columns");
         __shared__ __attribute__((aligned(16))) float lds[3][LB * TRSM_LDT];
-        const int b = blockIdx.y;
-        if (skipped[b])
+        const int NP = lv.NP, nblk = NP / LB;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nblk) * 8 + (blockIdx.x & 7), rb = slot % nblk;
+        if (b >= nfilters || skipped[b])
                 return;
-        const int n = d.n[b], NP = lv.NP;
+        const int n = d.n[b];
         const int nb = large_blocks(n);
-        if ((int)blockIdx.x >= nb)
+        if (rb >= nb)
                 return;
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * blockIdx.x + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
+        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
         const int a_off = li * TRSM_LDT + 4 * lg;
         asm volatile("" ::: "a0", "a255"); // the strip (see above)
         unsigned long long t0_ = 0, r0_ = 0;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
         {
                 if (tid == 0)
                 {
-                        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                        const size_t wg = blockIdx.x;
                         lv.Y[2 * wg] = (double)(__builtin_amdgcn_s_memtime() - t0_);
                         lv.Y[2 * wg + 1] = (double)(__builtin_amdgcn_s_memrealtime() - r0_);
                 }

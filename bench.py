@@ -360,6 +360,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=None, help="callbacks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-sub", action="store_true", help="skip the ekf64 / ukf64 sub-records")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the batch-1 latency and PCIe-inclusive legs (profiling runs: the timed steps are then the last launches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -415,8 +417,9 @@ def main():
             "roofline": roofline(wl, B, C, kernel_s),
         }
         if world == 1:
-            out["single_trajectory"] = single_trajectory_latency(wl, args.seed, min(C, 200), local, dev)
-            out["pcie_step_batch"] = pcie_step_batch(wl, args.seed, min(B, 256), 10 if large else 100, local, dev)
+            if not args.no_legs:
+                out["single_trajectory"] = single_trajectory_latency(wl, args.seed, min(C, 200), local, dev)
+                out["pcie_step_batch"] = pcie_step_batch(wl, args.seed, min(B, 256), 10 if large else 100, local, dev)
             if subs:
                 out["sub"] = subs
             sample = args.cpu_sample

@@ -140,7 +140,7 @@ int main(int argc, char **argv)
         };
         // ---- correctness of the product kernel on the last filter
         reset_G();
-        hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(NB, B), dim3(256), 0, 0, d, lv, dskip);
+        hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, B, dskip);
         CK(hipDeviceSynchronize());
         std::vector<float> V(M);
         CK(hipMemcpy(V.data(), dG + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
@@ -171,43 +171,40 @@ int main(int argc, char **argv)
         {
                 if (bb > B)
                         break;
-                const float m0 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(NB, bb), dim3(256), 0, 0, d, lv, dskip); }, 5);
+                const float m0 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lv, bb, dskip); }, 5);
                 std::printf("  %3d filters = %4d workgroups (%.2f per CU): %7.3f ms = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", bb, 17 * bb, 17.0 * bb / 256, m0,
                             fl * bb / B / (m0 * 1e-3) / 1e12, fl * bb / B / (m0 * 1e-3) / 1e12 / 157.3 * 100);
-        }
-        // ---- one workgroup per FILTER (grid (1, B)): every workgroup streams its own copy of L, nothing is shared through the L2 -- the access
-        // pattern of a Cholesky that keeps one filter on one CU
-        {
-                const float m1 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 0>), dim3(1, B), dim3(256), 0, 0, d, lv, dskip); }, 5);
-                std::printf("  one workgroup per filter, %d filters: %7.3f ms (a workgroup's sweep alone on its CU: ~0.19 ms when L is shared through the L2)\n", B, m1);
         }
         // ---- clock and cycles per MFMA inside the kernel: s_memtime (shader clock) and s_memrealtime (100 MHz) around the sweep of every workgroup
         {
                 double *dY;
                 const int bb = 15; // one workgroup per CU
-                CK(hipMalloc(&dY, sizeof(double) * 2 * NB * B));
+                CK(hipMalloc(&dY, sizeof(double) * 2 * NB * (B + 8)));
                 LargeView<float> lw = lv;
                 lw.Y = dY;
                 auto report = [&](const char *name) {
                         CK(hipDeviceSynchronize());
-                        std::vector<double> y(2 * NB * bb);
+                        std::vector<double> y(2 * NB * 8 * ((bb + 7) / 8));
                         CK(hipMemcpy(y.data(), dY, sizeof(double) * y.size(), hipMemcpyDeviceToHost));
                         double cyc = 0, real = 0;
-                        for (int i = 0; i < NB * bb; ++i)
-                                cyc += y[2 * i], real += y[2 * i + 1];
-                        cyc /= NB * bb, real /= NB * bb;
+                        int cnt = 0;
+                        for (size_t i = 0; i < y.size() / 2; ++i)
+                                if (y[2 * i] > 0)
+                                        cyc += y[2 * i], real += y[2 * i + 1], ++cnt;
+                        cyc /= cnt, real /= cnt;
                         std::printf("  %-28s per workgroup: %9.0f shader cycles, %7.2f us => %5.0f MHz, %5.1f cycles per MFMA per wave\n", name, cyc, real / 100.0,
                                     cyc / (real / 100.0), cyc / mfma_per_wave);
                 };
-                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                CK(hipMemset(dY, 0, sizeof(double) * 2 * NB * (B + 8)));
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("product");
-                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("no fetch");
-                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9 + 16>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 9 + 16>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("no fetch, no barrier");
-                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 11>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 11>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("no fetch/stash/barrier");
-                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 16>), dim3(NB, bb), dim3(256), 0, 0, d, lw, dskip);
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 16>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("no barrier");
                 CK(hipFree(dY));
         }
