@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
 ///   * the lower tile is read-modify-written in fp64 and its NEW value is stored, transposed, into the upper triangle (32 bytes per
 ///     lane and register quadruple) -- no read of the upper triangle, and P stays exactly symmetric.
 /// grid (8 * lower tiles * ceil(B/8)), 256 threads.
-template <int KC>
+template <int KC, int DIAG = 0>
 __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
 {
         constexpr int TB = 128;
@@ -982,6 +982,19 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
         }
         if (idle)
                 return;
+        if constexpr (DIAG & 1)
+        {
+                // diagnostic build only (tools/ubench/trsm_bench.hip): the K loop without the read-modify-write of P
+                float sres = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                                sres += acc[u][v][0] + acc[u][v][1] + acc[u][v][2] + acc[u][v][3];
+                if (sres == 12345.678f)
+                        P[0] = sres;
+                return;
+        }
         const bool mirror = (jt < rt || wc < wr);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -998,11 +1011,20 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
                                 if (row0 + r < n && col < n) // keep P's padding clean (row n of G is Y^T, not V)
                                 {
                                         double *pp = P + (size_t)(row0 + r) * NP + col;
-                                        nv4[r] = *pp - (double)acc[u][v][r];
-                                        *pp = nv4[r];
+                                        if constexpr (DIAG & 4) // diagnostic: stores only
+                                                nv4[r] = -(double)acc[u][v][r];
+                                        else
+                                                nv4[r] = *pp - (double)acc[u][v][r];
+                                        if constexpr (DIAG & 2) // diagnostic: loads only (one store that never happens keeps them alive)
+                                        {
+                                                if (nv4[r] == 1.2345e300)
+                                                        *pp = nv4[r];
+                                        }
+                                        else
+                                                *pp = nv4[r];
                                 }
                         }
-                        if (mirror && col < n)
+                        if (mirror && col < n && !(DIAG & 2))
                         {
                                 double *m = P + (size_t)col * NP + row0; // four consecutive rows of the tile = 32 contiguous bytes of the mirrored row
                                 if (row0 + 3 < n)

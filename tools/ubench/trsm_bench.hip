@@ -282,8 +282,12 @@ int main(int argc, char **argv)
                 const double sf = (ntile * (ntile + 1) / 2 - ntile * 0.25) * 2.0 * 128 * 128 * 1056 * B;
                 std::printf("  syrk_f32p64<32>  %8.3f ms for %d filters = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", ms, B, sf / (ms * 1e-3) / 1e12,
                             sf / (ms * 1e-3) / 1e12 / 157.3 * 100);
-                const float ms64 = time_ms([&]() { hipLaunchKernelGGL(large_syrk_f32p64<64>, grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
-                std::printf("  syrk_f32p64<64>  %8.3f ms\n", ms64);
+                const float msk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_f32p64<32> without the read-modify-write of P  %8.3f ms\n", msk);
+                const float msl = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 2>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_f32p64<32> epilogue loads only                 %8.3f ms\n", msl);
+                const float mss = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 4>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_f32p64<32> epilogue stores only                %8.3f ms\n", mss);
         }
         return 0;
 }
