@@ -75,6 +75,46 @@ struct Mat
         }
 };
 
+#ifdef ORC_WITH_EIGEN
+// Compile-gated variant (oracle/Makefile target `eigen`, built only where <eigen3/Eigen/Dense> exists): the dense
+// routines the reference takes from Eigen -- operator* (ekf.cpp:297,300-301,309-310; ukf.cpp:287-288,374,378,389-391),
+// MatrixXd::inverse() (ekf.cpp:301, ukf.cpp:378) and llt().matrixL() (ukf.cpp:280) -- are evaluated BY EIGEN on the column-major
+// MatrixXd the reference uses, so that tests/test_oracle_eigen.py can pin this file's hand-written versions of them (below) against
+// the library the reference links.  Everything else in this file is shared by both builds.
+} // namespace (re-opened below)
+#include <eigen3/Eigen/Dense>
+namespace
+{
+Eigen::MatrixXd to_eigen(const Mat &A)
+{
+        Eigen::MatrixXd E(A.r, A.c);
+        for (int i = 0; i < A.r; ++i)
+                for (int j = 0; j < A.c; ++j)
+                        E(i, j) = A(i, j);
+        return E;
+}
+Mat from_eigen(const Eigen::MatrixXd &E)
+{
+        Mat A((int)E.rows(), (int)E.cols());
+        for (int i = 0; i < A.r; ++i)
+                for (int j = 0; j < A.c; ++j)
+                        A(i, j) = E(i, j);
+        return A;
+}
+Mat mul(const Mat &A, const Mat &B)
+{
+        return from_eigen(to_eigen(A) * to_eigen(B));
+}
+Mat inverse(const Mat &S)
+{
+        return from_eigen(to_eigen(S).inverse());
+}
+Mat lltMatrixL(const Mat &A)
+{
+        const Eigen::MatrixXd L = to_eigen(A).llt().matrixL();
+        return from_eigen(L);
+}
+#else
 /// C = A * B, each coefficient a k-ascending dot product
 Mat mul(const Mat &A, const Mat &B)
 {
@@ -92,6 +132,8 @@ Mat mul(const Mat &A, const Mat &B)
         }
         return C;
 }
+
+#endif // ORC_WITH_EIGEN
 
 Mat transpose(const Mat &A)
 {
@@ -150,6 +192,7 @@ void conservativeResizeLike(Vec &v, const Vec &other)
         v = n;
 }
 
+#ifndef ORC_WITH_EIGEN
 /// MatrixXd::inverse() for a dynamic matrix = PartialPivLU(S).inverse() = solve(Identity)
 Mat inverse(const Mat &S)
 {
@@ -242,6 +285,7 @@ Mat lltMatrixL(const Mat &A)
         }
         return L;
 }
+#endif // !ORC_WITH_EIGEN
 
 // ---------------------------------------------------------------- include/awesome_slam/tools.h:44-66
 /// tools.h:44-50 -- all binary32
