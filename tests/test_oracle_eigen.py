@@ -16,7 +16,7 @@ EIGEN_LIB = os.path.join(ROOT, "oracle", "libaslam_oracle_eigen.so")
 CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-import tracegen as tg
+from awesomeslam_amd import trace as tg
 from oracle.c_oracle import CFilter
 kind, L, T, seed, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 tr = tg.make_traces(L, T, B=1, seed=seed)
