@@ -321,7 +321,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         else
                                 for (int k = 0; k < NB; ++k)
                                 {
-                                        hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                                        hipLaunchKernelGGL(large_potrf_inv_tiles<T>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, k, g.skip);
                                         if (k + 1 < NB)
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
@@ -332,7 +332,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 {
                         for (int k = 0; k < NB; ++k)
                         {
-                                hipLaunchKernelGGL(large_potrf_inv<T>, dim3(gb), dim3(64), 0, g.st, g.dv, g.v, k, g.skip);
+                                hipLaunchKernelGGL(large_potrf_inv_tiles<T>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, k, g.skip);
                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((2 * NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 0, g.skip);
                         }
                         hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);

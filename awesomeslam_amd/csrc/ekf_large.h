@@ -396,105 +396,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-/// value of v in lane `lane` (a compile-time constant after unrolling), as a wave-uniform scalar
-__device__ __forceinline__ float lane_bcast(float v, int lane)
-{
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ double lane_bcast(double v, int lane)
-{
-        return readlane_f64(v, lane);
-}
-
-/// 1/sqrt(x): hardware seed + one Newton step (the pivots are the serial spine of the factorisation)
-__device__ __forceinline__ float rsqrt_fast(float x)
-{
-        const float y = __builtin_amdgcn_rsqf(x);
-        return y * fmaf(-0.5f * x * y, y, 1.5f);
-}
-__device__ __forceinline__ double rsqrt_fast(double x)
-{
-        return rsqrt_newton(x);
-}
-
-/// Cholesky of a 64x64 diagonal block of S in place (lower; the strict upper part is zeroed) and the inverse of the
-/// factor -> Li, by ONE wave with the block in registers: lane i holds row i, column entries of other rows are
-/// broadcast with v_readlane, so the 64 dependent column steps run without LDS or barriers.  The inverse (lane c carries
-/// column c of L^-1) lets the panel below the block be eliminated as a matrix product on the MFMA unit (X L^-T = X Linv^T).
-/// S: first element of the block (row stride NP).  Returns false on a non-positive pivot.
-template <typename T> __device__ __forceinline__ bool large_potrf_block(T *S, int NP, T *Li, int lane)
-{
-        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-        constexpr int VW = 16 / sizeof(T);
-        T a[LB];
-#pragma unroll
-        for (int c = 0; c < LB; c += VW)
-        {
-                const vec_t v = *reinterpret_cast<const vec_t *>(S + (size_t)lane * NP + c);
-#pragma unroll
-                for (int q = 0; q < VW; ++q)
-                        a[c + q] = v[q];
-        }
-        // s[r] = running sum of row r of column `lane` of L^-1 (forward substitution in outer-product form): once column j
-        // of L is final, x_j = s[j] / L(j,j) and s[c] -= L(c,j) x_j reuse the very multipliers L(c,j) the factorisation has
-        // just broadcast, so the inverse costs one extra FMA per broadcast and no second pass
-        T sres[LB];
-#pragma unroll
-        for (int c = 0; c < LB; ++c)
-                sres[c] = (lane == c) ? (T)1 : (T)0;
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-        {
-                const T djj = lane_bcast(a[j], j);
-                if (!(djj > (T)0))
-                        bad = true;
-                const T rj = rsqrt_fast(djj);
-                a[j] = (lane >= j) ? a[j] * rj : (T)0; // column j of L
-                const T xj = sres[j] * rj;             // (L^-1)(j, lane)
-                sres[j] = xj;
-#pragma unroll
-                for (int c = j + 1; c < LB; ++c)
-                {
-                        const T lcj = lane_bcast(a[j], c);
-                        a[c] = fma(-a[j], lcj, a[c]); // A(i,c) -= L(i,j) L(c,j); entries above the diagonal are zeroed later
-                        sres[c] = fma(-lcj, xj, sres[c]);
-                        if (((c - j) & 7) == 0)
-                                __builtin_amdgcn_sched_barrier(0); // broadcasts in groups of 8: hoisting a whole column spills SGPRs
-                }
-                __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int c = 0; c < LB; c += VW)
-        {
-                vec_t v;
-#pragma unroll
-                for (int q = 0; q < VW; ++q)
-                        v[q] = a[c + q];
-                *reinterpret_cast<vec_t *>(S + (size_t)lane * NP + c) = v;
-        }
-#pragma unroll
-        for (int r = 0; r < LB; ++r)
-                Li[r * LB + lane] = sres[r];
-        return !bad;
-}
-
-/// Diagonal block k.  grid (B), 64 threads.  (Folding this into the tail of large_update_panel(k-1) was tried: inlined there the
-/// broadcasts spill 1 500 SGPRs and the panel kernel drops from 3 to 2 waves per SIMD; profiles/r02_experiments.md.)
-template <typename T> __global__ __launch_bounds__(64) void large_potrf_inv(DevView d, LargeView<T> lv, int k, const int *skipped)
-{
-        const int b = blockIdx.x;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        if (k >= large_blocks(n))
-                return;
-        T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
-        T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
-        const int lane = threadIdx.x;
-        if (!large_potrf_block(S, NP, Li, lane) && lane == 0)
-                atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
-}
+// (the diagonal blocks: large_potrf_inv_tiles in ekf_large_chol.h)
 
 /// virtual stacked matrix M = [S; G] (2*na rows): row pointer of virtual row vr
 template <typename T> __device__ __forceinline__ T *stacked_row(const LargeView<T> &lv, int b, int na, int vr)
@@ -507,7 +409,7 @@ template <typename T> __device__ __forceinline__ T *stacked_row(const LargeView<
 ///   C  = M(rt, k0) - sum_{k < k0} M(rt, k) L(k0, k)^T      left-looking update, K = 64 k0, MFMA
 ///   X  = C L(k0,k0)^-T = C Linv^T                           the panel "triangular solve" as a 64-deep MFMA product
 ///   S(rt, rt) -= X X^T  (blocks of S only)                  the diagonal blocks are kept up to date right-looking, so
-///                                                           large_potrf_inv finds block k0+1 ready when this kernel ends
+///                                                           large_potrf_inv_tiles finds block k0+1 ready when this kernel ends
 /// One read-modify-write of every tile per factorisation.  A workgroup takes TWO consecutive 64-row blocks (a 128x64 tile:
 /// the block row of L is staged once for both, 128 MFMAs per wave between barriers); the two halves are addressed
 /// independently because the pair may straddle the S / G boundary.  4 waves, wave w = rows 32w..32w+31 of the tile as

@@ -125,10 +125,59 @@ __device__ __forceinline__ bool factor_and_invert(double *t, int tid)
         }
         return ok;
 }
+
+/// L (zeros above the diagonal) -> the 64x64 block at `Sdiag` (row stride NP), Linv = R^T -> `Linv_out` [64][64]: thread = row r, 16-column
+/// segment q.  T = float or double.
+template <typename T> __device__ __forceinline__ void store_block(const double *t, T *Sdiag, int NP, T *Linv_out, int tid)
+{
+        const int r = tid >> 2, q = tid & 3, ti = r >> 4, a = r & 15;
+        T *ls = Sdiag + (size_t)r * NP + 16 * q;
+        T *io = Linv_out + r * LB + 16 * q;
+        const double *Ltile = Lt(const_cast<double *>(t), ti, min(q, ti)) + a * TLD;
+        const double *Rtile = Rt(const_cast<double *>(t), ti, min(q, ti)) + a;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+        {
+                ls[e] = (q <= ti) ? (T)Ltile[e] : (T)0;
+                io[e] = (q <= ti) ? (T)Rtile[e * TLD] : (T)0; // Linv(a, b) = R(b, a)
+        }
+}
 } // namespace chol64
 
+/// Diagonal block k of the multi-workgroup chain (few filters per launch: batch 1, configs[4]): Cholesky factor and its inverse.
+/// grid (B), 256 threads.  Round 1 did this with one wave holding the block in registers (lane = row, `v_readlane` broadcasts):
+/// 41 us per launch at batch 1, 17 launches = 42 % of a callback; the four-wave tile form of large_chol_resident takes its place.
+template <typename T> __global__ __launch_bounds__(256) void large_potrf_inv_tiles(DevView d, LargeView<T> lv, int k, const int *skipped)
+{
+        __shared__ __attribute__((aligned(16))) double tiles[chol64::TILES * TSZ];
+        const int b = blockIdx.x;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        if (k >= large_blocks(n))
+                return;
+        T *S = lv.S + (size_t)b * NP * NP + (size_t)k * LB * NP + k * LB;
+        T *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
+        const int tid = threadIdx.x;
+        {
+                const int r = tid >> 2, q = tid & 3, ti = r >> 4, a = r & 15;
+                if (q <= ti)
+                {
+                        const T *src = S + (size_t)r * NP + 16 * q;
+                        double *dst = chol64::Lt(tiles, ti, q) + a * TLD;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                                dst[e] = (double)src[e];
+                }
+        }
+        const bool ok = chol64::factor_and_invert(tiles, tid);
+        chol64::store_block(tiles, S, NP, Li, tid);
+        if (!ok && tid == 0)
+                atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
+}
+
 /// grid (B), 256 threads: the Cholesky factor of S (lower block triangle, in place) and the inverses of its diagonal blocks (lv.Linv)
-/// for filter blockIdx.x.  Status bit 4 (ASLAM_ST_NOT_PD) on a non-positive pivot, as large_potrf_inv.
+/// for filter blockIdx.x.  Status bit 4 (ASLAM_ST_NOT_PD) on a non-positive pivot.
 template <int NBMAX>
 __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeView<float> lv, const int *skipped)
 {
@@ -172,27 +221,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                         }
                 }
                 ok = chol64::factor_and_invert(tiles, tid) && ok;
-                // L(I,I) -> S (zeros above the diagonal), Linv_I -> lv.Linv: thread = row r, 16-column segment q
-                {
-                        const int r = tid >> 2, q = tid & 3, ti = r >> 4, a = r & 15;
-                        float *ls = Sb + ((size_t)LB * I + r) * NP + (size_t)LB * I + 16 * q;
-                        float *li_out = Linv + (size_t)I * LB * LB + r * LB + 16 * q;
-                        const double *Ltile = chol64::Lt(tiles, ti, min(q, ti)) + a * TLD;
-                        const double *Rtile = chol64::Rt(tiles, ti, min(q, ti)) + a;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                        {
-                                f4 lo, io;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                {
-                                        lo[e] = (q <= ti) ? (float)Ltile[4 * v + e] : 0.f;
-                                        io[e] = (q <= ti) ? (float)Rtile[(4 * v + e) * TLD] : 0.f; // Linv(a, b) = R(b, a)
-                                }
-                                *reinterpret_cast<f4 *>(ls + 4 * v) = lo;
-                                *reinterpret_cast<f4 *>(li_out + 4 * v) = io;
-                        }
-                }
+                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid);
                 // the next block row reads them back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
