@@ -69,6 +69,44 @@ template <int T> __device__ __forceinline__ void trsm_mfma_tile(f4 &c0, f4 &c1, 
                        "n"(4 * T + 3));
 }
 
+/// The same 16 MFMAs with the stash of the prefetched block (four ds_write_b128 per thread: rows r0 + 16 q of an LDS buffer, byte
+/// address `lds` for q = 0) issued BETWEEN them: a wave that is alone on its SIMD pays for every instruction that sits between two
+/// MFMA groups with an idle matrix pipe (the stash measured 1.6 of 46 cycles per MFMA as separate statements).  The compiler still
+/// sees pf as plain inputs and waits for their global loads in front of the statement.
+template <int T>
+__device__ __forceinline__ void trsm_mfma_tile_stash(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, const f4 (&pf)[4],
+                                                     unsigned lds)
+{
+        static_assert(T >= 0 && T < 64, "strip tile");
+        static_assert(TRSM_LDT * 16 * 4 == 4608, "ds_write offsets below");
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c12, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %6, a%c12, %1\n\t"
+                     "ds_write_b128 %18, %14\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %8, a%c12, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %10, a%c12, %3\n\t"
+                     "ds_write_b128 %18, %15 offset:4608\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %5, a%c13, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %7, a%c13, %1\n\t"
+                     "ds_write_b128 %18, %16 offset:9216\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %9, a%c13, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %11, a%c13, %3\n\t"
+                     "ds_write_b128 %18, %17 offset:13824"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(pf[0]),
+                       "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(lds)
+                     : "memory");
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c12, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %6, a%c12, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %8, a%c12, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %10, a%c12, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %5, a%c13, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %7, a%c13, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %9, a%c13, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %11, a%c13, %3"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                     : "v"(a0[2]), "v"(a0[3]), "v"(a1[2]), "v"(a1[3]), "v"(a2[2]), "v"(a2[3]), "v"(a3[2]), "v"(a3[3]), "n"(4 * T + 2), "n"(4 * T + 3));
+}
+
 /// the four 16-byte fragments (row tiles t = 0 .. 3) of column tile q of a staged 64x64 block
 __device__ __forceinline__ void trsm_frags(f4 (&a)[4], const float *buf, int a_off, int q)
 {
@@ -148,31 +186,44 @@ template <int K> __device__ __forceinline__ void trsm_keep(const f4 (&x)[4])
 // MFMAs of block i; the barrier sits 16 MFMAs behind the LDS traffic it waits for.
 
 /// cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ...  up to Linv_{nb-1} (which is then fetched
-/// again and again: the pipeline runs two blocks past the end).  Scalar state only, advanced with selects: a taken branch per
-/// block costs a single-wave-per-SIMD kernel more than the arithmetic.
+/// again and again: the pipeline runs two blocks past the end).  Scalar state only, advanced with selects, and the loads are BUFFER
+/// loads (resource + scalar byte offset of the block row + one 32-bit lane offset): with a single wave per SIMD every instruction
+/// between two MFMA groups is a bubble; two taken branches per block, or 64-bit vector address arithmetic per block (~300 of a
+/// block's ~2 800 cycles: trsm_bench, "no fetch" against "every fetch from one block"), cost more than the data.
 struct TrsmSeq
 {
         int k, j, nb, NP;
-        const float *rowp, *linvp; // L(k, 0) and Linv_k
-        int r0, c4;                // this thread's 16 bytes of a block: rows r0 + 16 q, columns c4 .. c4 + 3
+        unsigned offh, offl;       // byte offsets of L(k, 0) inside S and of Linv_k inside Linv (this filter's)
+        unsigned voh, vol;         // this thread's byte offset inside a block of L (row stride NP) / of Linv (row stride 64): row tid >> 4, columns 4 (tid & 15) ..
+        __amdgpu_buffer_rsrc_t rs, rl;
+        int pin = 0; // diagnostic (trsm_bench, DIAG & 32): every fetch reads block 0 of S -- L1 hits instead of L2 / HBM
         __device__ __forceinline__ TrsmSeq(const float *Sb, const float *Linv, int k0, int nb_, int NP_, int tid)
-            : k(k0), j(0), nb(nb_), NP(NP_), rowp(Sb + (size_t)(LB * k0) * NP_), linvp(Linv + (size_t)k0 * LB * LB), r0(tid >> 4), c4((tid & 15) * 4)
+            : k(k0), j(0), nb(nb_), NP(NP_), offh((unsigned)(LB * k0) * NP_ * 4u), offl((unsigned)k0 * LB * LB * 4u),
+              voh((unsigned)(((tid >> 4) * NP_ + (tid & 15) * 4) * 4)), vol((unsigned)(((tid >> 4) * LB + (tid & 15) * 4) * 4)),
+              rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Sb), 0, NP_ * NP_ * 4, 0x00020000)),
+              rl(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Linv), 0, LARGE_NB_MAX * LB * LB * 4, 0x00020000))
         {
         }
+        /// four 16-byte loads per thread: rows (tid >> 4) + 16 q of the block
         __device__ __forceinline__ void fetch(f4 (&pf)[4])
         {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 const bool hist = j < k;
-                const float *blk = hist ? rowp + LB * j : linvp;
-                const int ld = hist ? NP : LB;
-                const unsigned off = (unsigned)(r0 * ld + c4);
+                const __amdgpu_buffer_rsrc_t r = hist ? rs : rl;
+                const unsigned so = pin ? 0u : hist ? offh + (unsigned)(LB * 4 * j) : offl;
+                const unsigned ldb = (unsigned)(hist ? NP : LB) * 64u; // bytes between rows r and r + 16
+                const unsigned vo = hist ? voh : vol;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                        pf[q] = *reinterpret_cast<const f4 *>(blk + (size_t)(16 * q * ld) + off);
+                {
+                        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)(so + q * ldb), 0);
+                        pf[q] = (f4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                }
                 const bool adv = !hist && k + 1 < nb;
                 j = hist ? j + 1 : (adv ? 0 : j);
                 k += adv ? 1 : 0;
-                rowp += adv ? (size_t)LB * NP : 0;
-                linvp += adv ? LB * LB : 0;
+                offh += adv ? (unsigned)LB * NP * 4u : 0u;
+                offl += adv ? (unsigned)(LB * LB * 4) : 0u;
         }
 };
 
@@ -197,17 +248,26 @@ __device__ __forceinline__ void trsm_history_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&
         asm volatile("" ::: "memory");
         trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
         trsm_frags(a1, pp.cur, a_off, 3); // the last read of buffer `cur`
-        // block i + 2 -> LDS (fetched while block i - 1 was multiplied), block i + 3 -> registers
+        // The barrier of this block.  It orders (a) the stash of block i + 1 (third group of the PREVIOUS block) before the first read of that
+        // data (behind the third group of this block) and (b) every wave's reads of the previous block's buffer before the stash below
+        // overwrites it -- events a whole block apart, so a wave waits here only for skew, not for its own LDS traffic: the four reads just
+        // issued stay in flight (lgkmcnt(4), raw s_barrier; a __syncthreads() would drain them, and placed behind the stash and the global
+        // fetch it cost 3.6 - 5.5 of 46 cycles per MFMA).
+        if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the barrier -- racy)
+                asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+        else
+                asm volatile("" ::: "memory");
+        // block i + 2 -> LDS (fetched while block i - 1 was multiplied) between the MFMAs of the third group, block i + 3 -> registers behind it
         if constexpr (!(DIAG & 2))
-                trsm_stash(pp.far, pf, tid);
+        {
+                typedef __attribute__((address_space(3))) float lds_float;
+                const unsigned lds = (unsigned)(uintptr_t)(lds_float *)(pp.far + (tid >> 4) * TRSM_LDT + (tid & 15) * 4);
+                trsm_mfma_tile_stash<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3], pf, lds);
+        }
+        else
+                trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
         if constexpr (!(DIAG & 1))
                 seq.fetch(pf);
-        asm volatile("" ::: "memory");
-        trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
-        // the barrier of this block sits HERE, 16 MFMAs behind the LDS traffic it has to wait for: block i + 2 becomes visible (first read
-        // behind the third MFMA group of block i + 1), and buffer `cur` is free for block i + 3 (written behind the second group of block i + 1)
-        if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the barrier -- racy)
-                __syncthreads();
         trsm_frags(a0, pp.nxt, a_off, 0);
         asm volatile("" ::: "memory");
         trsm_mfma_tile<4 * J + 3>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
@@ -290,14 +350,16 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, Trs
                 a0[2] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 32 * TRSM_LDT + 32);
                 a0[3] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 32);
                 a0[0] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 48);
-                asm volatile("" ::: "memory");
+                // the barrier of this block (see trsm_history_pipe): the three reads above stay in flight
+                if constexpr (!(DIAG & 2) && !(DIAG & 16))
+                        asm volatile("s_waitcnt lgkmcnt(3)\n\ts_barrier" ::: "memory");
+                else
+                        asm volatile("" ::: "memory");
                 if constexpr (!(DIAG & 2))
                         trsm_stash(pp.far, pf, tid);
                 if constexpr (!(DIAG & 1))
                         seq.fetch(pf);
                 trsm_mfma_x<3>(x[0], x[1], x[2], x[3], a1[1], a1[2], a1[3], a1[3], c[1]);
-                if constexpr (!(DIAG & 2) && !(DIAG & 16))
-                        __syncthreads(); // as in trsm_history_pipe: behind 12 MFMAs
                 trsm_mfma_x<2>(x[0], x[1], x[2], x[3], a0[2], a0[3], a0[3], a0[3], c[2]);
                 trsm_frags(a1, pp.nxt, a_off, 1);
                 asm volatile("" ::: "memory");
@@ -374,6 +436,8 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
                 r0_ = __builtin_amdgcn_s_memrealtime();
         }
         TrsmSeq seq(lv.S + (size_t)b * NP * NP, lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB, 0, nb, NP, tid);
+        if constexpr (DIAG & 32)
+                seq.pin = 1;
         TrsmPipe pp = {lds[0], lds[1], lds[2]};
         f4 c[4];
         trsm_sweep<DIAG, false>(c, Grow, nb, seq, seq, pp, a_off, tid);

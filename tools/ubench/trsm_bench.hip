@@ -206,6 +206,8 @@ int main(int argc, char **argv)
                 report("no fetch/stash/barrier");
                 hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 16>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
                 report("no barrier");
+                hipLaunchKernelGGL((large_trsm_pipe<LARGE_NB_MAX, 8 + 32>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lw, bb, dskip);
+                report("every fetch from one block (L1)");
                 CK(hipFree(dY));
         }
         // ---- large_chol_resident: S (binary32 copy of the SPD matrix) -> L, Linv against the host factor; then its time
