@@ -12,8 +12,8 @@
 // (13 MB per filter from HBM, against 38 MB for the old panel), at the rate large_trsm_pipe already streams them.
 //
 // The diagonal block: C = S(I,I) - sum (binary32, from the MFMA accumulators) goes to LDS as binary64 16x16 tiles; four waves factor it
-// with the fp64 tile kernels of the small path (factor_diag_tile_fast + fp64 MFMA panel / trailing updates), build L(I,I)^-1 tile by
-// tile (Linv_ij = -Linv_ii sum_k L_ik Linv_kj), and write both back in binary32.
+// (16x16 diagonal tiles: one wave, in binary32 like the data; panel / trailing updates: fp64 MFMA on the tiles), build L(I,I)^-1 tile
+// by tile (Linv_ij = -Linv_ii sum_k L_ik Linv_kj), and write both back in binary32.
 #pragma once
 
 namespace aslam
@@ -45,10 +45,56 @@ __device__ __forceinline__ d4 xyt(const double *X, const double *Y, d4 acc, doub
         return acc;
 }
 
+/// Cholesky factor of the 16x16 diagonal tile `T` (binary64 in LDS, lower triangle valid) in place and the inverse of the factor -> `Ti`,
+/// computed in BINARY32: the data of this path is binary32 (S, L and every product), and the 16 dependent pivot steps are the serial spine of
+/// the diagonal blocks -- a dependent v_fma_f64 takes 32 cycles on gfx950 (7.6 k cycles per tile for factor_diag_tile_fast), a v_fma_f32 a
+/// quarter of that.  One wave; lane i < 16 owns row i (lanes 16-63 mirror), multipliers travel through v_readlane, the inverse rides on the
+/// same broadcasts (outer-product form, as factor_diag_tile_fast).  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool factor_diag_tile_f32(double *T, double *Ti, int lane)
+{
+        float a[16], s[16];
+        const int row = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+        {
+                a[c] = (float)T[row * TLD + c];
+                s[c] = (row == c) ? 1.f : 0.f;
+        }
+        auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+                const float d = bcast(a[j], j);
+                ok = ok && (d > 0.f);
+                const float y = __builtin_amdgcn_rsqf(d);
+                const float inv = y * fmaf(-0.5f * d * y, y, 1.5f); // one Newton step on the hardware seed
+                const float lij = a[j] * inv;                       // L(i, j) for i >= j
+                const float xj = s[j] * inv;                        // (L^-1)(j, lane)
+                a[j] = lij;
+                s[j] = xj;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c)
+                {
+                        const float lc = bcast(lij, c);
+                        a[c] = fmaf(-lij, lc, a[c]);
+                        s[c] = fmaf(-lc, xj, s[c]);
+                }
+        }
+        // one unmasked store per lane and entry: lanes 16-63 hold copies of rows 0-15 and write the same values to the same addresses
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+        {
+                T[row * TLD + c] = (c <= row) ? (double)a[c] : 0.0;
+                Ti[c * TLD + row] = (double)s[c]; // Linv(c, row): zero above the diagonal by construction
+        }
+        return ok;
+}
+
 /// In: the lower 4x4 tiles of a symmetric positive definite 64x64 matrix in Lt.  Out: its Cholesky factor in Lt (zeros above the
 /// diagonal of the diagonal tiles) and R = (L^-1)^T tiles.  256 threads; starts and ends with a barrier.  Returns false (on wave 0)
 /// on a non-positive pivot.
-__device__ __forceinline__ bool factor_and_invert(double *t, int tid)
+template <bool F32_DIAG> __device__ __forceinline__ bool factor_and_invert(double *t, int tid)
 {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lg = lane >> 4;
         bool ok = true;
@@ -57,7 +103,7 @@ __device__ __forceinline__ bool factor_and_invert(double *t, int tid)
         for (int kb = 0; kb < 4; ++kb)
         {
                 if (wave == 0)
-                        ok = factor_diag_tile_fast(Lt(t, kb, kb), Ti(t, kb), lane) && ok;
+                        ok = (F32_DIAG ? factor_diag_tile_f32(Lt(t, kb, kb), Ti(t, kb), lane) : factor_diag_tile_fast(Lt(t, kb, kb), Ti(t, kb), lane)) && ok;
                 __syncthreads();
                 // panel: L(ib, kb) = S(ib, kb) Linv_kb^T, one tile per wave; wave 3 (never has one) transposes Linv_kb into R(kb, kb)
                 const int ib = kb + 1 + wave;
@@ -170,7 +216,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_inv_til
                                 dst[e] = (double)src[e];
                 }
         }
-        const bool ok = chol64::factor_and_invert(tiles, tid);
+        const bool ok = chol64::factor_and_invert<sizeof(T) == 4>(tiles, tid); // binary32 mode: binary32 diagonal tiles
         chol64::store_block(tiles, S, NP, Li, tid);
         if (!ok && tid == 0)
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
@@ -220,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                                         T[r] = (double)c[t][r];
                         }
                 }
-                ok = chol64::factor_and_invert(tiles, tid) && ok;
+                ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
                 chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid);
                 // the next block row reads them back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

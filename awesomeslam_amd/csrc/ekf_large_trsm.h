@@ -291,11 +291,12 @@ __device__ __forceinline__ void trsm_chain_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&a1
 /// sets of block i -> a0 / a1.  The caller guarantees that no wave still reads the three buffers (a barrier since the last read).
 __device__ __forceinline__ void trsm_pipe_start(f4 (&pf)[4], f4 (&a0)[4], f4 (&a1)[4], TrsmPipe &pp, TrsmSeq &seq, int a_off, int tid)
 {
-        seq.fetch(pf);
-        trsm_stash(pp.cur, pf, tid);
-        seq.fetch(pf);
-        trsm_stash(pp.nxt, pf, tid);
+        // all three blocks are requested before the first is waited for: one exposed memory latency per start, not three (a0 / a1 are free here)
+        seq.fetch(a0);
+        seq.fetch(a1);
         seq.fetch(pf); // block i + 2: written to LDS during block i
+        trsm_stash(pp.cur, a0, tid);
+        trsm_stash(pp.nxt, a1, tid);
         __syncthreads();
         trsm_frags(a0, pp.cur, a_off, 0);
         trsm_frags(a1, pp.cur, a_off, 1);
