@@ -269,8 +269,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
 /// from the P rows it reads, re-forms the three pose rows of G it needs for H G (their P rows stay in L2), and writes G and S
 /// without G ever being read back.  Also copies Y^T into row n of G.  Threads run over landmark column pairs.
 /// P is binary64 in both modes and the products are formed in binary64; G and S are rounded to T on the way out (in fp32 mode
-/// that is the one rounding of G).  Only the lower triangle of S is consumed downstream, but whole rows are written: the
-/// row is in flight anyway.  grid (2 + NP/2, B), 256 threads.
+/// that is the one rounding of G).  Only the lower block triangle of S (with full diagonal blocks) is consumed downstream and written.  grid (2 + NP/2, B), 256 threads.
 template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevView d, LargeView<T> lv, const int *skipped)
 {
         const int b = blockIdx.y;
@@ -349,6 +348,9 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                         S[(size_t)(r0 + 1) * NP + c] = (T)srow(hb0, hb1, true, g0, g1, g2, ga, gb);
                 }
         }
+        // Only the lower block triangle of S and its 64x64 diagonal blocks are consumed downstream (the Cholesky kernels): the row of S
+        // stops at the end of the diagonal block of its last row -- 2.1 of the 4.7 MB of S per filter are never written.
+        const int slim = pose ? LB : LB * ((r0 + 1) / LB + 1);
         // ---- landmark column pairs
         for (int j = tid; j < nl; j += 256)
         {
@@ -363,9 +365,12 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                         G[ce] = (T)g0e, G[co] = (T)g0o;
                         G[NP + ce] = (T)g1e, G[NP + co] = (T)g1o;
                         G[2 * (size_t)NP + ce] = (T)g2e, G[2 * (size_t)NP + co] = (T)g2o;
-                        S[ce] = (T)g0e, S[co] = (T)g0o;
-                        S[NP + ce] = (T)g1e, S[NP + co] = (T)g1o;
-                        S[2 * (size_t)NP + ce] = (T)g2e, S[2 * (size_t)NP + co] = (T)g2o;
+                        if (ce < slim)
+                        {
+                                S[ce] = (T)g0e, S[co] = (T)g0o;
+                                S[NP + ce] = (T)g1e, S[NP + co] = (T)g1o;
+                                S[2 * (size_t)NP + ce] = (T)g2e, S[2 * (size_t)NP + co] = (T)g2o;
+                        }
                 }
                 else
                 {
@@ -375,14 +380,17 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                         T *ga = G + (size_t)r0 * NP, *gb = ga + NP, *sa = S + (size_t)r0 * NP, *sb = sa + NP;
                         ga[ce] = (T)gae, ga[co] = (T)gao;
                         gb[ce] = (T)gbe, gb[co] = (T)gbo;
-                        double se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
-                        double ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
-                        if (ce == r0)
-                                se += rm; // R on the diagonal
-                        if (co == r0 + 1)
-                                uo += rm;
-                        sa[ce] = (T)se, sa[co] = (T)so;
-                        sb[ce] = (T)ue, sb[co] = (T)uo;
+                        if (ce < slim)
+                        {
+                                double se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
+                                double ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
+                                if (ce == r0)
+                                        se += rm; // R on the diagonal
+                                if (co == r0 + 1)
+                                        uo += rm;
+                                sa[ce] = (T)se, sa[co] = (T)so;
+                                sb[ce] = (T)ue, sb[co] = (T)uo;
+                        }
                 }
         }
         // ---- zero padding columns n .. na-1
