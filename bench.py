@@ -56,16 +56,16 @@ def algorithmic_flops(kind, n):
 def executed_flops(workload, n):
     """Flops the kernels actually issue per callback (padded tiles, structure-blind products), from the launch geometry."""
     if workload == "ekf512":
-        nb = (n + 1 + 63) // 64  # 64-blocks of the stacked matrix [S; G; Y^T]
-        f = 0.0
-        for k in range(nb):
-            blocks = 2 * nb - k - 1  # row blocks below the diagonal block: rest of S, all of G
-            f += blocks * 2.0 * 64 * 64 * (64 * k)  # left-looking history
-            f += blocks * 2.0 * 64 * 64 * 64  # C Linv^T
-            f += (nb - k - 1) * 2.0 * 64 * 64 * 64  # diagonal blocks of S, right-looking
-            f += 2.0 * 64 ** 3 * (1.0 / 3.0 + 1.0 / 3.0)  # in-register potrf + inverse
+        # round-2 chain (binary32 products): large_chol_resident + large_trsm_pipe + large_syrk_f32p64
+        nb = (n + 1 + 63) // 64  # 64-blocks (row n of G carries Y^T)
+        hist = 2.0 * 64 ** 3  # one history block: 4 waves x 64 MFMAs x 2048 flop
+        close = hist * 10.0 / 16.0  # one closing block: the product with the lower-triangular (in 16-tiles) Linv_k, 40 MFMAs per wave
+        f = (nb - 1) * nb * (nb + 1) / 6.0 * hist + nb * (nb - 1) / 2.0 * close  # Cholesky of S: block row I = I (I + 1) / 2 history blocks (incl. the diagonal chain) + I closing blocks
+        f += nb * 2.0 * 64 ** 3 * (1.0 / 3.0 + 1.0 / 3.0)  # 64x64 diagonal factorisations + inverses
+        f += nb * (nb * (nb - 1) / 2.0 * hist + nb * close)  # V = G L^-T: nb row blocks x (136 history + 17 closing blocks)
         nt = (nb * 64 + 127) // 128
-        f += (nt * (nt + 1) // 2 - nt * 0.25) * 2.0 * 128 * 128 * (nb * 64)  # syrk lower tiles (upper quadrant of diagonal ones idle)
+        kend = min(nb * 64, (n + 31) // 32 * 32)
+        f += (nt * (nt + 1) // 2 - nt * 0.25) * 2.0 * 128 * 128 * kend  # syrk lower tiles (upper quadrant of diagonal ones idle), K loop up to n
         return f
     np_ = 16 * ((n + 15) // 16)
     if workload in ("ekf64", "ekf8"):
