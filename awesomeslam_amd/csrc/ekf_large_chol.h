@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
         float *Sb = lv.S + (size_t)b * NP * NP;
         float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
         asm volatile("" ::: "a0", "a255"); // the strip (ekf_large_trsm.h)
+        __shared__ unsigned sync_ctr; // the sweeps' wave synchronisation (TrsmPipe): counts on through all block rows
+        if (tid == 0)
+                sync_ctr = 0;
+        unsigned nsig = 0;
         bool ok = true;
 #pragma unroll 1
         for (int I = 0; I < nb; ++I)
@@ -250,9 +254,10 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 float *Srow = Sb + ((size_t)LB * I + 16 * wave + li) * NP + 4 * lg; // this lane's row of block row I (+ 4 lg)
                 TrsmSeq seq(Sb, Linv, 0, I, NP, tid);
                 const TrsmSeq seq_diag(Sb, Linv, I, I + 1, NP, tid); // the history blocks of the diagonal block: L(I, 0 .. I-1), this sweep's own output
-                TrsmPipe pp = {pipe, pipe + LB * TRSM_LDT, pipe + 2 * LB * TRSM_LDT};
+                TrsmPipe pp = {pipe, pipe + LB * TRSM_LDT, pipe + 2 * LB * TRSM_LDT, &sync_ctr, nsig, 0u};
                 f4 c[4];
                 trsm_sweep<0, true>(c, Srow, I, seq, seq_diag, pp, a_off, tid);
+                nsig = pp.nsig;
                 __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
                 // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle
 #pragma unroll

@@ -69,13 +69,49 @@ template <int T> __device__ __forceinline__ void trsm_mfma_tile(f4 &c0, f4 &c1, 
                        "n"(4 * T + 3));
 }
 
+/// The same 16 MFMAs with the read of the workgroup's synchronisation counter (TrsmPipe) riding along: ds_read_b32 ahead of the first
+/// MFMA, the wait for it and the move to a scalar register behind the last one (by then it has long arrived: no stall, and nothing of
+/// it sits between two MFMA groups).
+template <int T>
+__device__ __forceinline__ void trsm_mfma_tile_peek(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, unsigned ctr_lds,
+                                                    unsigned &seen)
+{
+        static_assert(T >= 0 && T < 64, "strip tile");
+        unsigned vtmp, sval;
+        asm volatile("ds_read_b32 %4, %26\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %6, a%c22, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c22, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %14, a%c22, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %18, a%c22, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %7, a%c23, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c23, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %15, a%c23, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %19, a%c23, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %8, a%c24, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %12, a%c24, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %16, a%c24, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %20, a%c24, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %9, a%c25, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %13, a%c25, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %17, a%c25, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %21, a%c25, %3\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %5, %4"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(vtmp), "=s"(sval)
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]),
+                       "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]), "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2),
+                       "n"(4 * T + 3), "v"(ctr_lds)
+                     : "memory");
+        seen = sval;
+}
+
 /// The same 16 MFMAs with the stash of the prefetched block (four ds_write_b128 per thread: rows r0 + 16 q of an LDS buffer, byte
 /// address `lds` for q = 0) issued BETWEEN them: a wave that is alone on its SIMD pays for every instruction that sits between two
 /// MFMA groups with an idle matrix pipe (the stash measured 1.6 of 46 cycles per MFMA as separate statements).  The compiler still
 /// sees pf as plain inputs and waits for their global loads in front of the statement.
-template <int T>
+template <int T, bool SIGNAL>
 __device__ __forceinline__ void trsm_mfma_tile_stash(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, const f4 (&pf)[4],
-                                                     unsigned lds)
+                                                     unsigned lds, unsigned ctr_lds)
 {
         static_assert(T >= 0 && T < 64, "strip tile");
         static_assert(TRSM_LDT * 16 * 4 == 4608, "ds_write offsets below");
@@ -95,6 +131,9 @@ __device__ __forceinline__ void trsm_mfma_tile_stash(f4 &c0, f4 &c1, f4 &c2, f4 
                      : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(pf[0]),
                        "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(lds)
                      : "memory");
+        // the signal of TrsmPipe: one lane adds 1 to the counter, queued behind this wave's reads of the block and its four ds_writes
+        if constexpr (SIGNAL)
+                asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(ctr_lds), "v"(1u) : "memory");
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c12, %0\n\t"
                      "v_mfma_f32_16x16x4_f32 %1, %6, a%c12, %1\n\t"
                      "v_mfma_f32_16x16x4_f32 %2, %8, a%c12, %2\n\t"
@@ -230,12 +269,48 @@ struct TrsmSeq
 struct TrsmPipe
 {
         float *cur, *nxt, *far; // LDS buffers of block i, i + 1, i + 2
+        // The per-block synchronisation of the four waves is a COUNTER in LDS, not s_barrier: a wave adds 1 behind its stash ("my reads of
+        // this block's buffer and my part of block i + 2 are in the LDS queue": the LDS executes a wave's instructions in order, so when
+        // the add lands they have landed) and checks, one block later and ahead of its next stash, that all four waves have done so.
+        // Signal and check are 48 MFMAs apart, so skew between the waves is absorbed instead of stalling every wave at every block
+        // (s_barrier cost 3 - 5 of 43 cycles per MFMA here: trsm_bench, "no barrier").
+        unsigned *ctr;   // LDS word, zero at kernel start
+        unsigned nsig;   // signals this wave has given
+        unsigned seen;   // last value read
+        __device__ __forceinline__ unsigned ctr_lds() const
+        {
+                typedef __attribute__((address_space(3))) unsigned lds_uint;
+                return (unsigned)(uintptr_t)(lds_uint *)ctr;
+        }
         __device__ __forceinline__ void rotate()
         {
                 float *t = cur;
                 cur = nxt;
                 nxt = far;
                 far = t;
+        }
+        __device__ __forceinline__ void signal(int lane)
+        {
+                if (lane == 0)
+                        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++nsig;
+        }
+        /// issue the read of the counter (its latency hides behind the MFMAs that follow)
+        __device__ __forceinline__ void peek()
+        {
+                seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+        /// all four waves have given `nsig` signals; the spin is bounded (a lost signal would otherwise hang the GPU: results are then wrong, the
+        /// parity tests say so)
+        __device__ __forceinline__ void wait()
+        {
+                if (__builtin_expect(seen < 4u * nsig, 0)) // wave-uniform; the usual case falls through
+                {
+                        unsigned v = seen;
+                        for (int spin = 0; v < 4u * nsig && spin < (1 << 22); ++spin)
+                                v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                }
+                asm volatile("" ::: "memory");
         }
 };
 
@@ -246,15 +321,16 @@ __device__ __forceinline__ void trsm_history_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&
         trsm_mfma_tile<4 * J + 0>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
         trsm_frags(a0, pp.cur, a_off, 2);
         asm volatile("" ::: "memory");
-        trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
+        if constexpr (!(DIAG & 2) && !(DIAG & 16))
+                trsm_mfma_tile_peek<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3], pp.ctr_lds(), pp.seen);
+        else
+                trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
         trsm_frags(a1, pp.cur, a_off, 3); // the last read of buffer `cur`
-        // The barrier of this block.  It orders (a) the stash of block i + 1 (third group of the PREVIOUS block) before the first read of that
-        // data (behind the third group of this block) and (b) every wave's reads of the previous block's buffer before the stash below
-        // overwrites it -- events a whole block apart, so a wave waits here only for skew, not for its own LDS traffic: the four reads just
-        // issued stay in flight (lgkmcnt(4), raw s_barrier; a __syncthreads() would drain them, and placed behind the stash and the global
-        // fetch it cost 3.6 - 5.5 of 46 cycles per MFMA).
-        if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the barrier -- racy)
-                asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+        // The synchronisation point of this block (TrsmPipe).  It orders (a) the stash of block i + 1 (third group of the PREVIOUS block) before
+        // the first read of that data (behind the third group of this block) and (b) every wave's reads of the previous block's buffer before
+        // the stash below overwrites it -- events a whole block apart.
+        if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the synchronisation -- racy)
+                pp.wait();
         else
                 asm volatile("" ::: "memory");
         // block i + 2 -> LDS (fetched while block i - 1 was multiplied) between the MFMAs of the third group, block i + 3 -> registers behind it
@@ -262,7 +338,9 @@ __device__ __forceinline__ void trsm_history_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&
         {
                 typedef __attribute__((address_space(3))) float lds_float;
                 const unsigned lds = (unsigned)(uintptr_t)(lds_float *)(pp.far + (tid >> 4) * TRSM_LDT + (tid & 15) * 4);
-                trsm_mfma_tile_stash<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3], pf, lds);
+                trsm_mfma_tile_stash<4 * J + 2, !(DIAG & 16)>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3], pf, lds, pp.ctr_lds());
+                if constexpr (!(DIAG & 16))
+                        ++pp.nsig;
         }
         else
                 trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
@@ -347,17 +425,23 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, Trs
                 for (int t = 0; t < 4; ++t)
                         x[t] = (f4){0.f, 0.f, 0.f, 0.f};
                 trsm_mfma_x<4>(x[0], x[1], x[2], x[3], a0[0], a0[1], a0[2], a0[3], c[0]);
+                if constexpr (!(DIAG & 2) && !(DIAG & 16))
+                        pp.peek();
                 // fragments (2,2), (3,2), (3,3) of Linv_k
                 a0[2] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 32 * TRSM_LDT + 32);
                 a0[3] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 32);
                 a0[0] = *reinterpret_cast<const f4 *>(pp.cur + a_off + 48 * TRSM_LDT + 48);
-                // the barrier of this block (see trsm_history_pipe): the three reads above stay in flight
+                // the synchronisation point of this block (see trsm_history_pipe): the three reads above stay in flight
                 if constexpr (!(DIAG & 2) && !(DIAG & 16))
-                        asm volatile("s_waitcnt lgkmcnt(3)\n\ts_barrier" ::: "memory");
+                        pp.wait();
                 else
                         asm volatile("" ::: "memory");
                 if constexpr (!(DIAG & 2))
+                {
                         trsm_stash(pp.far, pf, tid);
+                        if constexpr (!(DIAG & 16))
+                                pp.signal(tid & 63);
+                }
                 if constexpr (!(DIAG & 1))
                         seq.fetch(pf);
                 trsm_mfma_x<3>(x[0], x[1], x[2], x[3], a1[1], a1[2], a1[3], a1[3], c[1]);
@@ -439,7 +523,10 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
         TrsmSeq seq(lv.S + (size_t)b * NP * NP, lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB, 0, nb, NP, tid);
         if constexpr (DIAG & 32)
                 seq.pin = 1;
-        TrsmPipe pp = {lds[0], lds[1], lds[2]};
+        __shared__ unsigned sync_ctr;
+        if (tid == 0)
+                sync_ctr = 0; // (the first barrier of the sweep publishes it)
+        TrsmPipe pp = {lds[0], lds[1], lds[2], &sync_ctr, 0u, 0u};
         f4 c[4];
         trsm_sweep<DIAG, false>(c, Grow, nb, seq, seq, pp, a_off, tid);
         if constexpr (DIAG & 8)
