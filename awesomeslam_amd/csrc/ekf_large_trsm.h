@@ -43,97 +43,101 @@ __device__ __forceinline__ void trsm_stash(float *buf, const f4 (&pf)[4], int ti
 // v_accvgpr copies and 520 spilled registers.)  hipcc inserts no wait states inside or around inline assembly: the blocks end
 // in the s_nop a following VALU / store read of an MFMA result needs (16x16x4 f32: 8 passes).
 
-/// c[t] += A-fragments a[t] (one 16-byte LDS read each: four k values) x strip tile T, t = 0 .. 3: 16 MFMAs
-template <int T> __device__ __forceinline__ void trsm_mfma_tile(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3)
+// ---- MFMA groups that carry the LDS traffic of the block pipeline INSIDE their instruction stream.  A wave that is alone on its SIMD
+// pays ~10 cycles of idle matrix pipe for every instruction that sits between two MFMA groups (60 instructions per block were 9 of 41
+// cycles per MFMA), while LDS, scalar and vector-memory instructions placed between the MFMAs of a group issue in its shadow.  A group
+// of 16 MFMAs (strip tile T = 4 k-steps x 4 row tiles) is two statements: the first half (k-steps 0, 1) starts with the four 16-byte
+// fragment reads a LATER group needs -- row tiles t = 0 .. 3 of column tile Q at LDS byte address `rd` -- and ends with the wait for
+// them (eight MFMAs = 256 cycles later: they have arrived), so that the compiler never sees a register with a load in flight; the second
+// half (k-steps 2, 3) is MFMAs only.
+
+/// first half, plain
+template <int T, int Q>
+__device__ __forceinline__ void trsm_half_a(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, f4 (&o)[4], unsigned rd)
 {
-        static_assert(T >= 0 && T < 64, "strip tile");
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c20, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %8, a%c20, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %12, a%c20, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %16, a%c20, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %5, a%c21, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %9, a%c21, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %13, a%c21, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %17, a%c21, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %6, a%c22, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c22, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %14, a%c22, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %18, a%c22, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %7, a%c23, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c23, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %15, a%c23, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %19, a%c23, %3"
-                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-                     : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]),
-                       "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]), "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2),
-                       "n"(4 * T + 3));
+        static_assert(T >= 0 && T < 64 && TRSM_LDT * 16 * 4 == 4608, "strip tile; ds offsets");
+        asm volatile("ds_read_b128 %4, %18 offset:0+%c19\n\t"
+                     "ds_read_b128 %5, %18 offset:4608+%c19\n\t"
+                     "ds_read_b128 %6, %18 offset:9216+%c19\n\t"
+                     "ds_read_b128 %7, %18 offset:13824+%c19\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %8, a%c16, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c16, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %12, a%c16, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %14, a%c16, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %9, a%c17, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c17, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %13, a%c17, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %15, a%c17, %3\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(rd), "n"(64 * Q)
+                     : "memory");
 }
 
-/// The same 16 MFMAs with the read of the workgroup's synchronisation counter (TrsmPipe) riding along: ds_read_b32 ahead of the first
-/// MFMA, the wait for it and the move to a scalar register behind the last one (by then it has long arrived: no stall, and nothing of
-/// it sits between two MFMA groups).
-template <int T>
-__device__ __forceinline__ void trsm_mfma_tile_peek(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, unsigned ctr_lds,
-                                                    unsigned &seen)
+/// first half + the read of the synchronisation counter (TrsmPipe): `seen` is a scalar when the statement ends
+template <int T, int Q>
+__device__ __forceinline__ void trsm_half_a_peek(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, f4 (&o)[4], unsigned rd,
+                                                 unsigned ctr_lds, unsigned &seen)
 {
         static_assert(T >= 0 && T < 64, "strip tile");
         unsigned vtmp, sval;
-        asm volatile("ds_read_b32 %4, %26\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %6, a%c22, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c22, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %14, a%c22, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %18, a%c22, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %7, a%c23, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c23, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %15, a%c23, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %19, a%c23, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %8, a%c24, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %12, a%c24, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %16, a%c24, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %20, a%c24, %3\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %9, a%c25, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %13, a%c25, %1\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %17, a%c25, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %21, a%c25, %3\n\t"
+        asm volatile("ds_read_b32 %8, %22\n\t"
+                     "ds_read_b128 %4, %20 offset:0+%c21\n\t"
+                     "ds_read_b128 %5, %20 offset:4608+%c21\n\t"
+                     "ds_read_b128 %6, %20 offset:9216+%c21\n\t"
+                     "ds_read_b128 %7, %20 offset:13824+%c21\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %10, a%c18, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %12, a%c18, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %14, a%c18, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %16, a%c18, %3\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %11, a%c19, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %13, a%c19, %1\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %15, a%c19, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %17, a%c19, %3\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
-                     "v_readfirstlane_b32 %5, %4"
-                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(vtmp), "=s"(sval)
-                     : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]),
-                       "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]), "n"(4 * T), "n"(4 * T + 1), "n"(4 * T + 2),
-                       "n"(4 * T + 3), "v"(ctr_lds)
+                     "v_readfirstlane_b32 %9, %8"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(vtmp), "=s"(sval)
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(rd), "n"(64 * Q), "v"(ctr_lds)
                      : "memory");
         seen = sval;
 }
 
-/// The same 16 MFMAs with the stash of the prefetched block (four ds_write_b128 per thread: rows r0 + 16 q of an LDS buffer, byte
-/// address `lds` for q = 0) issued BETWEEN them: a wave that is alone on its SIMD pays for every instruction that sits between two
-/// MFMA groups with an idle matrix pipe (the stash measured 1.6 of 46 cycles per MFMA as separate statements).  The compiler still
-/// sees pf as plain inputs and waits for their global loads in front of the statement.
-template <int T, bool SIGNAL>
-__device__ __forceinline__ void trsm_mfma_tile_stash(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, const f4 (&pf)[4],
-                                                     unsigned lds, unsigned ctr_lds)
+/// first half + the stash of the prefetched block (four ds_write_b128 per thread: rows r0 + 16 q of an LDS buffer, byte address `lds` for
+/// q = 0) + the signal of TrsmPipe: one lane adds 1 to the counter, queued behind this wave's reads of the block and its four ds_writes.
+/// The compiler sees pf as plain inputs and waits for their global loads in front of the statement.
+template <int T, int Q>
+__device__ __forceinline__ void trsm_half_a_stash(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3, f4 (&o)[4], unsigned rd,
+                                                  const f4 (&pf)[4], unsigned lds, unsigned ctr_lds)
 {
         static_assert(T >= 0 && T < 64, "strip tile");
-        static_assert(TRSM_LDT * 16 * 4 == 4608, "ds_write offsets below");
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c12, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %6, a%c12, %1\n\t"
-                     "ds_write_b128 %18, %14\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %8, a%c12, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %10, a%c12, %3\n\t"
-                     "ds_write_b128 %18, %15 offset:4608\n\t"
-                     "v_mfma_f32_16x16x4_f32 %0, %5, a%c13, %0\n\t"
-                     "v_mfma_f32_16x16x4_f32 %1, %7, a%c13, %1\n\t"
-                     "ds_write_b128 %18, %16 offset:9216\n\t"
-                     "v_mfma_f32_16x16x4_f32 %2, %9, a%c13, %2\n\t"
-                     "v_mfma_f32_16x16x4_f32 %3, %11, a%c13, %3\n\t"
-                     "ds_write_b128 %18, %17 offset:13824"
-                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(pf[0]),
-                       "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(lds)
+        asm volatile("ds_read_b128 %4, %18 offset:0+%c19\n\t"
+                     "ds_read_b128 %5, %18 offset:4608+%c19\n\t"
+                     "ds_read_b128 %6, %18 offset:9216+%c19\n\t"
+                     "ds_read_b128 %7, %18 offset:13824+%c19\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %8, a%c16, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %10, a%c16, %1\n\t"
+                     "ds_write_b128 %24, %20\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %12, a%c16, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %14, a%c16, %3\n\t"
+                     "ds_write_b128 %24, %21 offset:4608\n\t"
+                     "v_mfma_f32_16x16x4_f32 %0, %9, a%c17, %0\n\t"
+                     "v_mfma_f32_16x16x4_f32 %1, %11, a%c17, %1\n\t"
+                     "ds_write_b128 %24, %22 offset:9216\n\t"
+                     "v_mfma_f32_16x16x4_f32 %2, %13, a%c17, %2\n\t"
+                     "v_mfma_f32_16x16x4_f32 %3, %15, a%c17, %3\n\t"
+                     "ds_write_b128 %24, %23 offset:13824\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %25, %26\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(a2[0]), "v"(a2[1]), "v"(a3[0]), "v"(a3[1]), "n"(4 * T), "n"(4 * T + 1), "v"(rd), "n"(64 * Q), "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(lds), "v"(ctr_lds), "v"(1u)
                      : "memory");
-        // the signal of TrsmPipe: one lane adds 1 to the counter, queued behind this wave's reads of the block and its four ds_writes
-        if constexpr (SIGNAL)
-                asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(ctr_lds), "v"(1u) : "memory");
+}
+
+/// second half: k-steps 2, 3
+template <int T> __device__ __forceinline__ void trsm_half_b(f4 &c0, f4 &c1, f4 &c2, f4 &c3, const f4 &a0, const f4 &a1, const f4 &a2, const f4 &a3)
+{
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, a%c12, %0\n\t"
                      "v_mfma_f32_16x16x4_f32 %1, %6, a%c12, %1\n\t"
                      "v_mfma_f32_16x16x4_f32 %2, %8, a%c12, %2\n\t"
@@ -318,39 +322,42 @@ struct TrsmPipe
 template <int J, int DIAG>
 __device__ __forceinline__ void trsm_history_pipe(f4 (&c)[4], f4 (&a0)[4], f4 (&a1)[4], f4 (&pf)[4], TrsmPipe &pp, TrsmSeq &seq, int a_off, int tid)
 {
-        trsm_mfma_tile<4 * J + 0>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
-        trsm_frags(a0, pp.cur, a_off, 2);
-        asm volatile("" ::: "memory");
+        typedef __attribute__((address_space(3))) float lds_float;
+        const unsigned rd_cur = (unsigned)(uintptr_t)(lds_float *)(pp.cur + a_off), rd_nxt = (unsigned)(uintptr_t)(lds_float *)(pp.nxt + a_off);
+        f4 a2[4], a3[4]; // column tiles 2 and 3 of this block; a0 / a1 leave as column tiles 0 / 1 of the next one
+        // group 0 (column tile 0), reading column tile 2 of this block
+        trsm_half_a<4 * J + 0, 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3], a2, rd_cur);
+        trsm_half_b<4 * J + 0>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
+        // group 1 (column tile 1), reading column tile 3 -- the last read of buffer `cur` -- and the synchronisation counter
         if constexpr (!(DIAG & 2) && !(DIAG & 16))
-                trsm_mfma_tile_peek<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3], pp.ctr_lds(), pp.seen);
+                trsm_half_a_peek<4 * J + 1, 3>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3], a3, rd_cur, pp.ctr_lds(), pp.seen);
         else
-                trsm_mfma_tile<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
-        trsm_frags(a1, pp.cur, a_off, 3); // the last read of buffer `cur`
+                trsm_half_a<4 * J + 1, 3>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3], a3, rd_cur);
+        trsm_half_b<4 * J + 1>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
         // The synchronisation point of this block (TrsmPipe).  It orders (a) the stash of block i + 1 (third group of the PREVIOUS block) before
-        // the first read of that data (behind the third group of this block) and (b) every wave's reads of the previous block's buffer before
+        // the first read of that data (in the third group of this block) and (b) every wave's reads of the previous block's buffer before
         // the stash below overwrites it -- events a whole block apart.
         if constexpr (!(DIAG & 2) && !(DIAG & 16)) // (16: timing experiment without the synchronisation -- racy)
                 pp.wait();
         else
                 asm volatile("" ::: "memory");
-        // block i + 2 -> LDS (fetched while block i - 1 was multiplied) between the MFMAs of the third group, block i + 3 -> registers behind it
+        // group 2 (column tile 2): block i + 2 -> LDS (fetched while block i - 1 was multiplied) and the signal between its MFMAs, reading
+        // column tile 0 of the NEXT block; block i + 3 -> registers behind it
         if constexpr (!(DIAG & 2))
         {
-                typedef __attribute__((address_space(3))) float lds_float;
                 const unsigned lds = (unsigned)(uintptr_t)(lds_float *)(pp.far + (tid >> 4) * TRSM_LDT + (tid & 15) * 4);
-                trsm_mfma_tile_stash<4 * J + 2, !(DIAG & 16)>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3], pf, lds, pp.ctr_lds());
+                trsm_half_a_stash<4 * J + 2, 0>(c[0], c[1], c[2], c[3], a2[0], a2[1], a2[2], a2[3], a0, rd_nxt, pf, lds, pp.ctr_lds());
                 if constexpr (!(DIAG & 16))
                         ++pp.nsig;
         }
         else
-                trsm_mfma_tile<4 * J + 2>(c[0], c[1], c[2], c[3], a0[0], a0[1], a0[2], a0[3]);
+                trsm_half_a<4 * J + 2, 0>(c[0], c[1], c[2], c[3], a2[0], a2[1], a2[2], a2[3], a0, rd_nxt);
+        trsm_half_b<4 * J + 2>(c[0], c[1], c[2], c[3], a2[0], a2[1], a2[2], a2[3]);
         if constexpr (!(DIAG & 1))
                 seq.fetch(pf);
-        trsm_frags(a0, pp.nxt, a_off, 0);
-        asm volatile("" ::: "memory");
-        trsm_mfma_tile<4 * J + 3>(c[0], c[1], c[2], c[3], a1[0], a1[1], a1[2], a1[3]);
-        trsm_frags(a1, pp.nxt, a_off, 1);
-        asm volatile("" ::: "memory");
+        // group 3 (column tile 3), reading column tile 1 of the next block
+        trsm_half_a<4 * J + 3, 1>(c[0], c[1], c[2], c[3], a3[0], a3[1], a3[2], a3[3], a1, rd_nxt);
+        trsm_half_b<4 * J + 3>(c[0], c[1], c[2], c[3], a3[0], a3[1], a3[2], a3[3]);
         pp.rotate();
 }
 
