@@ -247,16 +247,17 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
         if (tid == 0)
                 sync_ctr = 0;
         unsigned nsig = 0;
+        const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(Sb, 0, NP * NP * 4, 0x00020000);
         bool ok = true;
 #pragma unroll 1
         for (int I = 0; I < nb; ++I)
         {
-                float *Srow = Sb + ((size_t)LB * I + 16 * wave + li) * NP + 4 * lg; // this lane's row of block row I (+ 4 lg)
+                const unsigned vs = (unsigned)(((LB * I + 16 * wave + li) * NP + 4 * lg) * 4); // this lane's row of block row I (+ 4 lg floats), bytes
                 TrsmSeq seq(Sb, Linv, 0, I, NP, tid);
                 const TrsmSeq seq_diag(Sb, Linv, I, I + 1, NP, tid); // the history blocks of the diagonal block: L(I, 0 .. I-1), this sweep's own output
                 TrsmPipe pp = {pipe, pipe + LB * TRSM_LDT, pipe + 2 * LB * TRSM_LDT, &sync_ctr, nsig, 0u};
                 f4 c[4];
-                trsm_sweep<0, true>(c, Srow, I, seq, seq_diag, pp, a_off, tid);
+                trsm_sweep<0, true>(c, rsb, vs, I, seq, seq_diag, pp, a_off, tid);
                 nsig = pp.nsig;
                 __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
                 // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle

@@ -388,20 +388,27 @@ __device__ __forceinline__ void trsm_pipe_start(f4 (&pf)[4], f4 (&a0)[4], f4 (&a
 }
 
 /// The sweep of one 16-row strip per wave over block columns 0 .. nbk - 1:  X(:, k) = (G(:, k) - sum_{j<k} X(:, j) L(k, j)^T) Linv_k^T,
-/// written over G and kept in the strip.  `Grow`: this lane's row (+ 4 lg).
+/// written over G and kept in the strip.  `rg`: buffer resource of the matrix the rows live in, `vg`: byte offset of this lane's row (+ 4 lg
+/// floats) in it -- buffer loads / stores with a scalar column offset: no 64-bit vector address arithmetic between MFMA groups.
 /// CHOL (large_chol_resident: the rows are block row nbk of S itself): block column nbk follows, closed differently -- its history
 /// blocks are L(nbk, j) = the X(:, j) this very sweep has just stored, so the pipeline is drained and restarted in front of them, and
 /// the sweep returns  c = S(nbk, nbk) - sum_j X(:, j) X(:, j)^T  (this wave's 16 rows: c[t][r] = column 16 t + 4 lg + r of row li)
 /// for the caller to factor.  `seq` walks Linv_0; L(1,0), Linv_1; ... (nb = nbk), `seq_diag` (CHOL only) starts at L(nbk, 0).
 template <int DIAG, bool CHOL>
-__device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, TrsmSeq &seq, const TrsmSeq &seq_diag, TrsmPipe &pp, int a_off, int tid)
+__device__ __forceinline__ void trsm_sweep(f4 (&c)[4], __amdgpu_buffer_rsrc_t rg, unsigned vg, int nbk, TrsmSeq &seq, const TrsmSeq &seq_diag, TrsmPipe &pp,
+                                           int a_off, int tid)
 {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        auto gload = [&](int col) { // four floats of this lane's row at column `col` (wave-uniform) + 4 lg
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)vg, col * 4, 0);
+                return (f4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        };
         f4 pf[4], a0[4], a1[4], g0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
         {
                 c[t] = (f4){0.f, 0.f, 0.f, 0.f};
-                g0[t] = *reinterpret_cast<const f4 *>(Grow + 16 * t); // G[row][16 t + 4 lg .. +3]
+                g0[t] = gload(16 * t); // G[row][16 t + 4 lg .. +3]
         }
         if (!CHOL || nbk > 0)
                 trsm_pipe_start(pf, a0, a1, pp, seq, a_off, tid);
@@ -461,7 +468,8 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, Trs
                 asm volatile("s_nop 15" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); // MFMA result -> store data
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                        *reinterpret_cast<f4 *>(Grow + LB * k + 16 * t) = x[t];
+                        __builtin_amdgcn_raw_buffer_store_b128((u4){__float_as_uint(x[t][0]), __float_as_uint(x[t][1]), __float_as_uint(x[t][2]), __float_as_uint(x[t][3])}, rg,
+                                                               (int)vg, (LB * k + 16 * t) * 4, 0);
                 switch (k)
                 {
 #define ASLAM_TRSM_KEEP(K)                                                                                             \
@@ -494,7 +502,7 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], float *Grow, int nbk, Trs
                 for (int t = 0; t < 4; ++t)
                 {
                         c[t] = (f4){0.f, 0.f, 0.f, 0.f};
-                        g0[t] = *reinterpret_cast<const f4 *>(Grow + LB * kn + 16 * t);
+                        g0[t] = gload(LB * kn + 16 * t);
                 }
                 pp.rotate();
         }
@@ -518,7 +526,8 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
         if (rb >= nb)
                 return;
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *Grow = lv.G + ((size_t)b * NP + (size_t)LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(lv.G + (size_t)b * NP * NP, 0, NP * NP * 4, 0x00020000);
+        const unsigned vg = (unsigned)(((LB * rb + 16 * wave + li) * NP + 4 * lg) * 4); // this lane's row of G
         const int a_off = li * TRSM_LDT + 4 * lg;
         asm volatile("" ::: "a0", "a255"); // the strip (see above)
         unsigned long long t0_ = 0, r0_ = 0;
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
                 sync_ctr = 0; // (the first barrier of the sweep publishes it)
         TrsmPipe pp = {lds[0], lds[1], lds[2], &sync_ctr, 0u, 0u};
         f4 c[4];
-        trsm_sweep<DIAG, false>(c, Grow, nb, seq, seq, pp, a_off, tid);
+        trsm_sweep<DIAG, false>(c, rg, vg, nb, seq, seq, pp, a_off, tid);
         if constexpr (DIAG & 8)
         {
                 if (tid == 0)
