@@ -776,8 +776,9 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
 ///     consecutive floats k = 16 c + 4 g .. + 3 of its row and uses component r in MFMA step r, i.e. the contraction index is
 ///     visited in a permuted order, the same for both operands (row stride KC + 8 floats: conflict-free for ds_read_b128);
 ///   * the K loop stops at the filter's size n (columns n .. of V are zero), not at the padded size;
-///   * the lower tile is read-modify-written in fp64 and its NEW value is stored, transposed, into the upper triangle (32 bytes per
-///     lane and register quadruple) -- no read of the upper triangle, and P stays exactly symmetric.
+///   * the lower tile is read-modify-written in fp64 (16 bytes per lane and access: the products are formed as B x A^T so that a lane
+///     holds four consecutive columns of a row) and its NEW value is stored, transposed, into the upper triangle -- no read of the upper
+///     triangle, and P stays exactly symmetric.
 /// grid (8 * lower tiles * ceil(B/8)), 256 threads.
 template <int KC, int DIAG = 0>
 __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
                                         for (int u = 0; u < 4; ++u)
 #pragma unroll
                                                 for (int v = 0; v < 4; ++v)
-                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], bv[v][r], acc[u][v], 0, 0, 0);
+                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[v][r], av[u][r], acc[u][v], 0, 0, 0); // B x A^T: see the epilogue
                         }
                 }
                 else
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
                                                                 const f4 b4 = *reinterpret_cast<const f4 *>(&Bs[b_off + 16 * v * LD + 16 * c]);
 #pragma unroll
                                                                 for (int r = 0; r < 4; ++r)
-                                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], b4[r], acc[u][v], 0, 0, 0);
+                                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[r], a4[r], acc[u][v], 0, 0, 0);
                                                         }
                 }
                 __syncthreads();
@@ -906,52 +907,50 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
                 return;
         }
         const bool mirror = (jt < rt || wc < wr);
+        {
+                // The K loop multiplies B x A^T (operands swapped), so a lane's four registers are four consecutive COLUMNS of one row of the
+                // lower tile: 32 contiguous bytes, two 16-byte loads and stores per 16x16 tile; the mirror image is the strided side (four
+                // 8-byte stores).  With A x B^T (four consecutive rows per lane: four 8-byte loads + stores, 16-byte mirror stores) the
+                // epilogue cost 0.66 ms per 256 filters against 0.33 ms (trsm_bench).
+                typedef double d2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                {
-                        const int col = jt * TB + wc + 16 * v + li;
-                        const int row0 = rt * TB + wr + 16 * u + 4 * lg;
-                        double nv4[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                        for (int v = 0; v < 4; ++v)
                         {
-                                nv4[r] = 0.0;
-                                if (row0 + r < n && col < n) // keep P's padding clean (row n of G is Y^T, not V)
+                                const int row = rt * TB + wr + 16 * u + li;
+                                const int col0 = jt * TB + wc + 16 * v + 4 * lg;
+                                if (row >= n || col0 >= n)
+                                        continue;
+                                double *pp = P + (size_t)row * NP + col0;
+                                double nv4[4];
+                                if (col0 + 3 < n)
                                 {
-                                        double *pp = P + (size_t)(row0 + r) * NP + col;
-                                        if constexpr (DIAG & 4) // diagnostic: stores only
-                                                nv4[r] = -(double)acc[u][v][r];
-                                        else
-                                                nv4[r] = *pp - (double)acc[u][v][r];
-                                        if constexpr (DIAG & 2) // diagnostic: loads only (one store that never happens keeps them alive)
-                                        {
-                                                if (nv4[r] == 1.2345e300)
-                                                        *pp = nv4[r];
-                                        }
-                                        else
-                                                *pp = nv4[r];
-                                }
-                        }
-                        if (mirror && col < n && !(DIAG & 2))
-                        {
-                                double *m = P + (size_t)col * NP + row0; // four consecutive rows of the tile = 32 contiguous bytes of the mirrored row
-                                if (row0 + 3 < n)
-                                {
-                                        typedef double d2 __attribute__((ext_vector_type(2)));
-                                        *reinterpret_cast<d2 *>(m) = (d2){nv4[0], nv4[1]};
-                                        *reinterpret_cast<d2 *>(m + 2) = (d2){nv4[2], nv4[3]};
+                                        const d2 o0 = *reinterpret_cast<const d2 *>(pp), o1 = *reinterpret_cast<const d2 *>(pp + 2);
+                                        nv4[0] = o0[0] - (double)acc[u][v][0], nv4[1] = o0[1] - (double)acc[u][v][1];
+                                        nv4[2] = o1[0] - (double)acc[u][v][2], nv4[3] = o1[1] - (double)acc[u][v][3];
+                                        *reinterpret_cast<d2 *>(pp) = (d2){nv4[0], nv4[1]};
+                                        *reinterpret_cast<d2 *>(pp + 2) = (d2){nv4[2], nv4[3]};
                                 }
                                 else
                                 {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
-                                                if (row0 + r < n)
-                                                        m[r] = nv4[r];
+                                                if (col0 + r < n)
+                                                {
+                                                        nv4[r] = pp[r] - (double)acc[u][v][r];
+                                                        pp[r] = nv4[r];
+                                                }
+                                }
+                                if (mirror)
+                                {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                                if (col0 + r < n)
+                                                        P[(size_t)(col0 + r) * NP + row] = nv4[r];
                                 }
                         }
-                }
+        }
 }
 
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay
@@ -970,8 +969,16 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
         const T *vrow = lv.G + ((size_t)b * NP + a) * NP;
         const T *q = lv.G + ((size_t)b * NP + n) * NP;
         double acc = 0.0;
-        for (int j = lane; j < n; j += 64)
-                acc += (double)vrow[j] * (double)q[j];
+        // 16 bytes per lane and load (rows are 256-byte aligned: NP is a multiple of 64); columns n .. of both rows are zero
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int VW = 16 / sizeof(T);
+        for (int j = VW * lane; j < n; j += 64 * VW)
+        {
+                const vec_t v = *reinterpret_cast<const vec_t *>(vrow + j), w = *reinterpret_cast<const vec_t *>(q + j);
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                        acc = fma((double)v[e], (double)w[e], acc);
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)
                 acc += __shfl_xor(acc, off);

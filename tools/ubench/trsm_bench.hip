@@ -286,10 +286,6 @@ int main(int argc, char **argv)
                             sf / (ms * 1e-3) / 1e12 / 157.3 * 100);
                 const float msk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
                 std::printf("  syrk_f32p64<32> without the read-modify-write of P  %8.3f ms\n", msk);
-                const float msl = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 2>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
-                std::printf("  syrk_f32p64<32> epilogue loads only                 %8.3f ms\n", msl);
-                const float mss = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 4>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
-                std::printf("  syrk_f32p64<32> epilogue stores only                %8.3f ms\n", mss);
         }
         return 0;
 }
