@@ -68,6 +68,27 @@ def test_single_slam_on_synthetic_state(n, steps, dtype, built, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident"])
+def test_indefinite_innovation_covariance_is_flagged(dtype, built, monkeypatch):
+    """S = H P H^T + R without a Cholesky factor (here: a covariance with a negative landmark variance) must raise the sticky
+    ASLAM_ST_NOT_PD bit in every form of the factorisation -- the reference would go on with the NaNs of `inverse()` silently
+    (ekf.cpp:301); the bit is what this path reports instead -- and must leave the other filter of the batch alone."""
+    from awesomeslam_amd.core import Core, F32, F64, ST_NOT_PD
+
+    dtype = chol_mode(dtype, monkeypatch)
+    n = 203
+    X, Z, P = synth(n, 7)
+    bad = P.copy()
+    bad[100, 100] = -50.0  # a landmark coordinate with a negative variance, far beyond R = 0.2
+    core = Core("ekf", n + 1, batch=2, max_obs=4, max_wait=4, dtype=F32 if dtype == "f32" else F64)
+    core.set_state(0, n, X, Z, P)
+    core.set_state(1, n, X, Z, bad)
+    core.ekf_step(0, 0.2, 0.1, 1.0, Z, 0.07, -0.03)
+    core.ekf_step(1, 0.2, 0.1, 1.0, Z, 0.07, -0.03)
+    assert core.status(0) == 0
+    assert core.status(1) & ST_NOT_PD
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident"])
 @pytest.mark.parametrize("L,T,kw", [(80, 150, dict(seed=61)), (100, 80, dict(seed=62, sensor_every=2, dt_mode="random"))])
 def test_replay_parity(L, T, kw, dtype, built, monkeypatch):
     import torch
