@@ -224,7 +224,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_inv_til
 
 /// grid (B), 256 threads: the Cholesky factor of S (lower block triangle, in place) and the inverses of its diagonal blocks (lv.Linv)
 /// for filter blockIdx.x.  Status bit 4 (ASLAM_ST_NOT_PD) on a non-positive pivot.
-template <int NBMAX>
+template <int NBMAX, int STAMP = 0>
 __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeView<float> lv, const int *skipped)
 {
         static_assert(NBMAX == 17, "trsm_sweep lists 17 block columns");
@@ -249,6 +249,16 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
         unsigned nsig = 0;
         const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(Sb, 0, NP * NP * 4, 0x00020000);
         bool ok = true;
+        // STAMP (diagnostic build, tools/ubench/trsm_bench.hip): shader cycles of workgroup 0 by phase -> lv.Y[0 .. 3]: sweeps, conversion, diagonal
+        // factorisation, stores + drain
+        unsigned long long tph[4] = {0, 0, 0, 0}, tm_ = STAMP ? __builtin_amdgcn_s_memtime() : 0, tn_ = 0;
+#define ASLAM_PH(i)                                                                                                    \
+        if constexpr (STAMP)                                                                                           \
+        {                                                                                                              \
+                tn_ = __builtin_amdgcn_s_memtime();                                                                    \
+                tph[i] += tn_ - tm_;                                                                                   \
+                tm_ = tn_;                                                                                             \
+        }
 #pragma unroll 1
         for (int I = 0; I < nb; ++I)
         {
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 trsm_sweep<0, true>(c, rsb, vs, I, seq, seq_diag, pp, a_off, tid);
                 nsig = pp.nsig;
                 __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
+                ASLAM_PH(0)
                 // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -272,12 +283,20 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                                         T[r] = (double)c[t][r];
                         }
                 }
+                ASLAM_PH(1)
                 ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
+                ASLAM_PH(2)
                 chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid);
                 // the next block row reads them back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                ASLAM_PH(3)
         }
+#undef ASLAM_PH
+        if constexpr (STAMP)
+                if (tid == 0 && b == 0)
+                        for (int i = 0; i < 4; ++i)
+                                lv.Y[i] = (double)tph[i];
         if (!ok && tid == 0)
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
 }

@@ -268,6 +268,21 @@ int main(int argc, char **argv)
                         CK(hipEventElapsedTime(&ms, e0, e1));
                         std::printf("  chol_resident %3d filters: %7.3f ms\n", bb, ms);
                 }
+                {
+                        double *dY;
+                        CK(hipMalloc(&dY, sizeof(double) * 4));
+                        LargeView<float> lw = lv;
+                        lw.Y = dY;
+                        reset_S();
+                        hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX, 1>), dim3(B), dim3(256), 0, 0, dc, lw, dskip);
+                        CK(hipDeviceSynchronize());
+                        double y[4];
+                        CK(hipMemcpy(y, dY, sizeof(y), hipMemcpyDeviceToHost));
+                        std::printf("  chol_resident, workgroup 0, shader cycles by phase over the 17 block rows: sweeps %.0f, C -> tiles %.0f, 64x64 factor + inverse %.0f, "
+                                    "stores + drain %.0f (per block row: %.0f / %.0f / %.0f / %.0f)\n",
+                                    y[0], y[1], y[2], y[3], y[0] / 17, y[1] / 17, y[2] / 17, y[3] / 17);
+                        CK(hipFree(dY));
+                }
                 // restore the factor for the kernels timed below
                 for (int b = 0; b < B; ++b)
                 {
