@@ -309,7 +309,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         auto chain = [&](const Group &g, int s) {
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
-                hipLaunchKernelGGL(large_build_GS<T>, dim3(2 + NP / 2, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                hipLaunchKernelGGL(large_build_GS<T>, dim3(1 + (NP / 2 + GS_ROW_PAIRS - 1) / GS_ROW_PAIRS, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                 const int ntile = (NP + 127) / 128;
                 const dim3 syrk_grid(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8));
                 if constexpr (sizeof(T) == 4)

@@ -269,7 +269,9 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
 /// from the P rows it reads, re-forms the three pose rows of G it needs for H G (their P rows stay in L2), and writes G and S
 /// without G ever being read back.  Also copies Y^T into row n of G.  Threads run over landmark column pairs.
 /// P is binary64 in both modes and the products are formed in binary64; G and S are rounded to T on the way out (in fp32 mode
-/// that is the one rounding of G).  Only the lower block triangle of S (with full diagonal blocks) is consumed downstream and written.  grid (2 + NP/2, B), 256 threads.
+/// that is the one rounding of G).  Only the lower block triangle of S (with full diagonal blocks) is consumed downstream and written.  grid (1 + ceil((NP / 2) / GS_ROW_PAIRS), B), 256 threads: workgroup 0 the pose rows, the others GS_ROW_PAIRS landmark row pairs each.
+constexpr int GS_ROW_PAIRS = 2;
+
 template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevView d, LargeView<T> lv, const int *skipped)
 {
         const int b = blockIdx.y;
@@ -285,42 +287,63 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
         const double rm = (double)KR;
         const int tid = threadIdx.x;
         const bool pose = (blockIdx.x == 0);
-        const int r0 = pose ? 0 : 3 + 2 * ((int)blockIdx.x - 1); // first row of this workgroup
+        constexpr int RP = GS_ROW_PAIRS; // landmark row pairs per workgroup: the pose rows of G and the H coefficients of a column pair are formed once for all of them
+        const int r0 = pose ? 0 : 3 + 2 * RP * ((int)blockIdx.x - 1); // first row of this workgroup
         if (r0 >= na)
                 return;
-        if (!pose && r0 >= n)
+        int nlive = 0; // leading row pairs that are landmarks (rows < n; n is odd, so a pair never straddles n)
+        if (!pose)
         {
-                // padding rows r0, r0+1: G = 0 (row n: Y^T), S = identity
-                for (int rr = r0; rr < min(r0 + 2, na); ++rr)
+                for (int rp = 0; rp < RP; ++rp)
                 {
-                        T *grow = G + (size_t)rr * NP, *srow = S + (size_t)rr * NP;
-                        const double *Y = lv.Y + (size_t)b * NP;
-                        for (int c = tid; c < na; c += 256)
+                        const int ra = r0 + 2 * rp;
+                        if (ra >= na)
+                                break;
+                        if (ra < n)
                         {
-                                grow[c] = (rr == n && c < n) ? (T)Y[c] : (T)0;
-                                srow[c] = (c == rr) ? (T)1 : (T)0;
+                                nlive = rp + 1;
+                                continue;
+                        }
+                        // padding rows ra, ra+1: G = 0 (row n: Y^T), S = identity
+                        for (int rr = ra; rr < min(ra + 2, na); ++rr)
+                        {
+                                T *grow = G + (size_t)rr * NP, *srow = S + (size_t)rr * NP;
+                                const double *Y = lv.Y + (size_t)b * NP;
+                                for (int c = tid; c < na; c += 256)
+                                {
+                                        grow[c] = (rr == n && c < n) ? (T)Y[c] : (T)0;
+                                        srow[c] = (c == rr) ? (T)1 : (T)0;
+                                }
                         }
                 }
-                return;
+                if (nlive == 0)
+                        return;
         }
         // G(a, :) for one row a of P: columns 0..2 copy P, landmark column pair j mixes (t0, t1, t2, ta, tb) with H_j
         const double *p0 = P, *p1 = P + NP, *p2 = P + 2 * (size_t)NP;
         const double t00 = p0[0], t01 = p0[1], t02 = p0[2], t10 = p1[0], t11 = p1[1], t12 = p1[2], t20 = p2[0], t21 = p2[1], t22 = p2[2];
-        const double *pa = P + (size_t)r0 * NP, *pb = pa + NP; // landmark rows (unused by the pose workgroup)
-        double ta0 = 0, ta1 = 0, ta2 = 0, tb0 = 0, tb1 = 0, tb2 = 0, ha0 = 0, ha1 = 0, hb0 = 0, hb1 = 0;
-        if (!pose)
+        const double *pa[RP], *pb[RP]; // landmark rows (unused by the pose workgroup)
+        double ta0[RP], ta1[RP], ta2[RP], tb0[RP], tb1[RP], tb2[RP], ha0[RP], ha1[RP], hb0[RP], hb1[RP];
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp)
         {
-                ta0 = pa[0], ta1 = pa[1], ta2 = pa[2];
-                tb0 = pb[0], tb1 = pb[1], tb2 = pb[2];
-                const double *hr = Hc + 4 * ((r0 - 3) >> 1);
-                ha0 = hr[0], ha1 = hr[1], hb0 = hr[2], hb1 = hr[3]; // H rows r0 (range) and r0+1 (bearing)
+                const int ra = min(r0 + 2 * rp, n - 2); // (pairs beyond nlive are never used: keep their addresses valid)
+                pa[rp] = P + (size_t)ra * NP, pb[rp] = pa[rp] + NP;
+                ta0[rp] = ta1[rp] = ta2[rp] = tb0[rp] = tb1[rp] = tb2[rp] = ha0[rp] = ha1[rp] = hb0[rp] = hb1[rp] = 0.0;
+                if (!pose && rp < nlive)
+                {
+                        ta0[rp] = pa[rp][0], ta1[rp] = pa[rp][1], ta2[rp] = pa[rp][2];
+                        tb0[rp] = pb[rp][0], tb1[rp] = pb[rp][1], tb2[rp] = pb[rp][2];
+                        const double *hr = Hc + 4 * ((ra - 3) >> 1);
+                        ha0[rp] = hr[0], ha1[rp] = hr[1], hb0[rp] = hr[2], hb1[rp] = hr[3]; // H rows ra (range) and ra+1 (bearing)
+                }
         }
         auto grow = [](double h00, double h01, double h10, double h11, double t0, double t1, double t2, double ta, double tb, double &ge,
                        double &go) {
                 ge = h00 * t0 + h01 * t1 - h00 * ta - h01 * tb;
                 go = h10 * t0 + h11 * t1 - t2 - h10 * ta - h11 * tb;
         };
-        // S(r, c) = (H G)(r, c) for landmark row r = r0 (+1): ha g0 + hb g1 [- g2] - ha ga - hb gb
+        // S(r, c) = (H G)(r, c) for landmark row r = ra (+1): ha g0 + hb g1 [- g2] - ha ga - hb gb
         auto srow = [](double ha, double hb, bool odd, double g0, double g1, double g2, double ga, double gb) -> double {
                 double v = ha * g0 + hb * g1;
                 if (odd)
@@ -341,16 +364,21 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                 }
                 else
                 {
-                        const double ga = pa[c], gb = pb[c];
-                        G[(size_t)r0 * NP + c] = (T)ga;
-                        G[(size_t)(r0 + 1) * NP + c] = (T)gb;
-                        S[(size_t)r0 * NP + c] = (T)srow(ha0, ha1, false, g0, g1, g2, ga, gb);
-                        S[(size_t)(r0 + 1) * NP + c] = (T)srow(hb0, hb1, true, g0, g1, g2, ga, gb);
+#pragma unroll
+                        for (int rp = 0; rp < RP; ++rp)
+                                if (rp < nlive)
+                                {
+                                        const int ra = r0 + 2 * rp;
+                                        const double ga = pa[rp][c], gb = pb[rp][c];
+                                        G[(size_t)ra * NP + c] = (T)ga;
+                                        G[(size_t)(ra + 1) * NP + c] = (T)gb;
+                                        S[(size_t)ra * NP + c] = (T)srow(ha0[rp], ha1[rp], false, g0, g1, g2, ga, gb);
+                                        S[(size_t)(ra + 1) * NP + c] = (T)srow(hb0[rp], hb1[rp], true, g0, g1, g2, ga, gb);
+                                }
                 }
         }
-        // Only the lower block triangle of S and its 64x64 diagonal blocks are consumed downstream (the Cholesky kernels): the row of S
-        // stops at the end of the diagonal block of its last row -- 2.1 of the 4.7 MB of S per filter are never written.
-        const int slim = pose ? LB : LB * ((r0 + 1) / LB + 1);
+        // Only the lower block triangle of S and its 64x64 diagonal blocks are consumed downstream (the Cholesky kernels): a row of S
+        // stops at the end of the diagonal block of its pair's last row -- 2.1 of the 4.7 MB of S per filter are never written.
         // ---- landmark column pairs
         for (int j = tid; j < nl; j += 256)
         {
@@ -365,7 +393,7 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                         G[ce] = (T)g0e, G[co] = (T)g0o;
                         G[NP + ce] = (T)g1e, G[NP + co] = (T)g1o;
                         G[2 * (size_t)NP + ce] = (T)g2e, G[2 * (size_t)NP + co] = (T)g2o;
-                        if (ce < slim)
+                        if (ce < LB)
                         {
                                 S[ce] = (T)g0e, S[co] = (T)g0o;
                                 S[NP + ce] = (T)g1e, S[NP + co] = (T)g1o;
@@ -374,27 +402,35 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
                 }
                 else
                 {
-                        double gae, gao, gbe, gbo;
-                        grow(h00, h01, h10, h11, ta0, ta1, ta2, pa[ce], pa[co], gae, gao);
-                        grow(h00, h01, h10, h11, tb0, tb1, tb2, pb[ce], pb[co], gbe, gbo);
-                        T *ga = G + (size_t)r0 * NP, *gb = ga + NP, *sa = S + (size_t)r0 * NP, *sb = sa + NP;
-                        ga[ce] = (T)gae, ga[co] = (T)gao;
-                        gb[ce] = (T)gbe, gb[co] = (T)gbo;
-                        if (ce < slim)
-                        {
-                                double se = srow(ha0, ha1, false, g0e, g1e, g2e, gae, gbe), so = srow(ha0, ha1, false, g0o, g1o, g2o, gao, gbo);
-                                double ue = srow(hb0, hb1, true, g0e, g1e, g2e, gae, gbe), uo = srow(hb0, hb1, true, g0o, g1o, g2o, gao, gbo);
-                                if (ce == r0)
-                                        se += rm; // R on the diagonal
-                                if (co == r0 + 1)
-                                        uo += rm;
-                                sa[ce] = (T)se, sa[co] = (T)so;
-                                sb[ce] = (T)ue, sb[co] = (T)uo;
-                        }
+#pragma unroll
+                        for (int rp = 0; rp < RP; ++rp)
+                                if (rp < nlive)
+                                {
+                                        const int ra = r0 + 2 * rp;
+                                        double gae, gao, gbe, gbo;
+                                        grow(h00, h01, h10, h11, ta0[rp], ta1[rp], ta2[rp], pa[rp][ce], pa[rp][co], gae, gao);
+                                        grow(h00, h01, h10, h11, tb0[rp], tb1[rp], tb2[rp], pb[rp][ce], pb[rp][co], gbe, gbo);
+                                        T *ga = G + (size_t)ra * NP, *gb = ga + NP, *sa = S + (size_t)ra * NP, *sb = sa + NP;
+                                        ga[ce] = (T)gae, ga[co] = (T)gao;
+                                        gb[ce] = (T)gbe, gb[co] = (T)gbo;
+                                        if (ce < LB * ((ra + 1) / LB + 1))
+                                        {
+                                                double se = srow(ha0[rp], ha1[rp], false, g0e, g1e, g2e, gae, gbe),
+                                                       so = srow(ha0[rp], ha1[rp], false, g0o, g1o, g2o, gao, gbo);
+                                                double ue = srow(hb0[rp], hb1[rp], true, g0e, g1e, g2e, gae, gbe),
+                                                       uo = srow(hb0[rp], hb1[rp], true, g0o, g1o, g2o, gao, gbo);
+                                                if (ce == ra)
+                                                        se += rm; // R on the diagonal
+                                                if (co == ra + 1)
+                                                        uo += rm;
+                                                sa[ce] = (T)se, sa[co] = (T)so;
+                                                sb[ce] = (T)ue, sb[co] = (T)uo;
+                                        }
+                                }
                 }
         }
         // ---- zero padding columns n .. na-1
-        const int nrows = pose ? 3 : 2;
+        const int nrows = pose ? 3 : 2 * nlive;
         for (int idx = tid; idx < nrows * (na - n); idx += 256)
         {
                 const int rr = r0 + idx / (na - n), c = n + idx % (na - n);
