@@ -270,7 +270,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
 /// without G ever being read back.  Also copies Y^T into row n of G.  Threads run over landmark column pairs.
 /// P is binary64 in both modes and the products are formed in binary64; G and S are rounded to T on the way out (in fp32 mode
 /// that is the one rounding of G).  Only the lower block triangle of S (with full diagonal blocks) is consumed downstream and written.  grid (1 + ceil((NP / 2) / GS_ROW_PAIRS), B), 256 threads: workgroup 0 the pose rows, the others GS_ROW_PAIRS landmark row pairs each.
-constexpr int GS_ROW_PAIRS = 2;
+constexpr int GS_ROW_PAIRS = 2; // 4: slower (29.1 k against 29.7 k filter-steps/s on one stream), 1: 28.5 k
 
 template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevView d, LargeView<T> lv, const int *skipped)
 {
