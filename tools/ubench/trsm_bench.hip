@@ -1,7 +1,12 @@
-// trsm_bench.hip -- stand-alone timing + correctness harness for large_trsm_pipe / large_syrk_f32p64 (ekf_large*.h), round 2.
-// Random SPD S -> host Cholesky (double) -> L and the inverses of its 64x64 diagonal blocks in binary32; random G; the kernel's V
-// against a host triangular solve for the last filter; then timings of the product kernel and of its diagnostic variants
-// (DIAG bit 0: no global fetch of L, bit 1: no LDS stash / barrier, bit 4: no barrier, bit 3: in-kernel clock stamps).
+// trsm_bench.hip -- stand-alone correctness + timing harness for the kernels of the large-state EKF's binary32 chain
+// (ekf_large_trsm.h, ekf_large_chol.h, large_syrk_f32p64 in ekf_large.h), round 2.
+// Random SPD S -> host Cholesky (double) -> L and the inverses of its 64x64 diagonal blocks in binary32; random G.  Checks:
+// large_trsm_pipe's V against a host triangular solve, large_chol_resident's L and Linv against the host factor.  Timings: the product
+// kernels at several batch sizes, and diagnostic variants of large_trsm_pipe with one part of the block pipeline removed, stamped inside
+// the kernel with s_memtime / s_memrealtime (cycles per MFMA and wave).  DIAG bits of large_trsm_pipe: 1 = no global fetch of the L
+// blocks (stale LDS), 2 = no LDS stash and no synchronisation, 16 = no synchronisation (racy), 32 = every fetch reads one block (L1 hits:
+// separates the issue cost of the fetch from its latency), 8 = stamps.  large_chol_resident<17, 1>: phase stamps.  large_syrk_f32p64<32, 1>:
+// the K loop without the read-modify-write of P.  The numbers quoted in DESIGN.md and profiles/r02_experiments.md come from this program.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I awesomeslam_amd/csrc tools/ubench/trsm_bench.hip -o /tmp/trsm_bench && /tmp/trsm_bench [filters]
 #include <hip/hip_runtime.h>
 
