@@ -306,6 +306,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 return g;
         };
         const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : Bz >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
+        static const bool syrk_bf16x3 = !(std::getenv("ASLAM_SYRK_BF16X3") && std::atoi(std::getenv("ASLAM_SYRK_BF16X3")) == 0); // 0: fp32 MFMA products (A/B)
         auto chain = [&](const Group &g, int s) {
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
@@ -326,7 +327,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
                         hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
-                        hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        if (syrk_bf16x3)
+                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        else
+                                hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 else
                 {

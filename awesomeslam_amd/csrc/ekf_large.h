@@ -989,6 +989,217 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
         }
 }
 
+/// P -= V V^T with the binary32 products formed on the BF16 matrix pipe ("bf16x3"): every float is the exact sum of three bf16 pieces of
+/// eight mantissa bits (a = a1 + a2 + a3), and  a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1):  six v_mfma_f32_16x16x32_bf16
+/// (16x16x32 per instruction, fp32 accumulation, bf16 x bf16 products exact) do the work of eight v_mfma_f32_16x16x4_f32 at twice
+/// the rate, and the dropped terms (2^-24 |a b| and below) are smaller than the rounding of a binary32 product chain
+/// (tools/ubench/mfma_bf16x3.hip: 6.3e-8 of sum |a b| against 1.5e-7 for an fp32 FMA chain; 294 against 149 T fp32-equivalent FLOP/s).
+/// Same tiling, tile -> workgroup map, K-loop bounds and read-modify-write epilogue as large_syrk_f32p64; the slab of V is split into its
+/// three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; rows of 80 bytes: conflict-free 16-byte reads),
+/// the operand of an MFMA is ONE 16-byte read (row l & 15, k = 8 (l >> 4) .. + 7).
+template <int DIAG = 0>
+__global__ __launch_bounds__(256, 2) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
+{
+        constexpr int TB = 128, KC = 32;
+        constexpr int LDB = KC + 8; // bf16 per LDS row: 80 bytes
+        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        __shared__ __attribute__((aligned(16))) unsigned short As[3][TB * LDB];
+        __shared__ __attribute__((aligned(16))) unsigned short Bs[3][TB * LDB];
+        const int ntile = (lv.NP + TB - 1) / TB, nlow = ntile * (ntile + 1) / 2;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nlow) * 8 + (blockIdx.x & 7);
+        if (b >= nfilters || skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int na = large_blocks(n) * LB;
+        const int tl = slot % nlow;
+        int rt = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while ((rt + 1) * (rt + 2) / 2 <= tl)
+                ++rt;
+        while (rt * (rt + 1) / 2 > tl)
+                --rt;
+        const int jt = tl - rt * (rt + 1) / 2;
+        if (rt * TB >= n)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+        const float *G = lv.G + (size_t)b * NP * NP;
+        double *P = lv.P + (size_t)b * NP * NP;
+        // staging: 8 lanes cover the 32 columns of a slab row with 16-byte loads; 32 rows per pass
+        constexpr int LPR = KC / 4, RPP = 256 / LPR, NPASS = TB / RPP;
+        const int lrow = tid / LPR, lc0 = (tid % LPR) * 4;
+        const float *Ap[NPASS], *Bp[NPASS];
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+        {
+                Ap[q] = G + (size_t)min(rt * TB + lrow + RPP * q, na - 1) * NP + lc0;
+                Bp[q] = G + (size_t)min(jt * TB + lrow + RPP * q, na - 1) * NP + lc0;
+        }
+        f4 acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        acc[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
+        f4 ta[NPASS], tb[NPASS];
+        auto fetch = [&](int kc) {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q)
+                {
+                        ta[q] = *reinterpret_cast<const f4 *>(Ap[q] + kc);
+                        tb[q] = *reinterpret_cast<const f4 *>(Bp[q] + kc);
+                }
+        };
+        // four floats -> their three bf16 planes: x = h + m + l up to 2^-25 |x|
+        auto stash = [&](unsigned short (&S)[3][TB * LDB], int off, const f4 &x) {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                        // round to nearest (not truncation: truncated pieces all carry the sign of x, the dropped terms a2 b3 + a3 b2 then
+                        // have the sign of the product, and V V^T comes out systematically small: the covariance error grew 1.5x faster)
+                        const unsigned u = (__float_as_uint(x[e]) + 0x8000u) & 0xffff0000u;
+                        const float r1 = x[e] - __uint_as_float(u);
+                        const unsigned u1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
+                        const float r2 = r1 - __uint_as_float(u1);
+                        h[e] = u, m[e] = u1, l[e] = __float_as_uint(r2) + 0x8000u;
+                }
+                *reinterpret_cast<u2 *>(&S[0][off]) = (u2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+                *reinterpret_cast<u2 *>(&S[1][off]) = (u2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+                *reinterpret_cast<u2 *>(&S[2][off]) = (u2){(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+        };
+        const bool idle = (rt == jt && wc > wr); // upper quadrant of a diagonal tile: the mirror image of its lower one
+        // A diagonal quadrant holds (I, J) and (J, I).  With binary32 MFMA products the two sums are bit-identical; here the six partial
+        // products of the pair enter them in different orders, so only J <= I is computed and the mirror image is stored from it, element
+        // by element inside the 16x16 tiles on the diagonal: P stays exactly symmetric.
+        const bool diagq = (rt == jt && wc == wr);
+        const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
+        const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
+        const int kend = min(na, (n + KC - 1) / KC * KC); // columns n .. na-1 of V are zero (G = P H^T is zero there and L is the identity)
+        const int a_off = (wr + li) * LDB + 8 * lg, b_off = (wc + li) * LDB + 8 * lg;
+        fetch(0);
+        for (int kc = 0; kc < kend; kc += KC)
+        {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q)
+                {
+                        stash(As, (lrow + RPP * q) * LDB + lc0, ta[q]);
+                        stash(Bs, (lrow + RPP * q) * LDB + lc0, tb[q]);
+                }
+                __syncthreads();
+                if (kc + KC < kend)
+                        fetch(kc + KC);
+                u4 bq[4][3];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                                bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * v * LDB]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                        if (u < nu)
+                        {
+                                u4 ap[3];
+#pragma unroll
+                                for (int p = 0; p < 3; ++p)
+                                        ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                        if (v < nv && !(diagq && v > u))
+                                        {
+                                                // B x A^T (see the epilogue), small terms first
+#define ASLAM_MM(pb, pa)                                                                                               \
+        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bq[v][pb]), __builtin_bit_cast(bf8, ap[pa]), acc[u][v], 0, 0, 0)
+                                                ASLAM_MM(0, 2);
+                                                ASLAM_MM(1, 1);
+                                                ASLAM_MM(2, 0);
+                                                ASLAM_MM(0, 1);
+                                                ASLAM_MM(1, 0);
+                                                ASLAM_MM(0, 0);
+#undef ASLAM_MM
+                                        }
+                        }
+                __syncthreads();
+        }
+        if (idle)
+                return;
+        if constexpr (DIAG & 1)
+        {
+                // diagnostic build only (tools/ubench/trsm_bench.hip): the K loop without the read-modify-write of P
+                float sres = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                                sres += acc[u][v][0] + acc[u][v][1] + acc[u][v][2] + acc[u][v][3];
+                if (sres == 12345.678f)
+                        P[0] = sres;
+                return;
+        }
+        const bool mirror = (jt < rt || wc < wr);
+        {
+                // The K loop multiplies B x A^T (operands swapped), so a lane's four registers are four consecutive COLUMNS of one row of the
+                // lower tile: 32 contiguous bytes, two 16-byte loads and stores per 16x16 tile; the mirror image is the strided side (four
+                // 8-byte stores).  With A x B^T (four consecutive rows per lane: four 8-byte loads + stores, 16-byte mirror stores) the
+                // epilogue cost 0.66 ms per 256 filters against 0.33 ms (trsm_bench).
+                typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                        {
+                                const int row = rt * TB + wr + 16 * u + li;
+                                const int col0 = jt * TB + wc + 16 * v + 4 * lg;
+                                if (row >= n || col0 >= n || (diagq && v > u))
+                                        continue;
+                                if (diagq && v == u)
+                                {
+                                        // 16x16 tile on the diagonal: the elements J <= I, each with its mirror image
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                                if (col0 + r <= row)
+                                                {
+                                                        double *pe = P + (size_t)row * NP + col0 + r;
+                                                        const double pn = *pe - (double)acc[u][v][r];
+                                                        *pe = pn;
+                                                        if (col0 + r < row)
+                                                                P[(size_t)(col0 + r) * NP + row] = pn;
+                                                }
+                                        continue;
+                                }
+                                double *pp = P + (size_t)row * NP + col0;
+                                double nv4[4];
+                                if (col0 + 3 < n)
+                                {
+                                        const d2 o0 = *reinterpret_cast<const d2 *>(pp), o1 = *reinterpret_cast<const d2 *>(pp + 2);
+                                        nv4[0] = o0[0] - (double)acc[u][v][0], nv4[1] = o0[1] - (double)acc[u][v][1];
+                                        nv4[2] = o1[0] - (double)acc[u][v][2], nv4[3] = o1[1] - (double)acc[u][v][3];
+                                        *reinterpret_cast<d2 *>(pp) = (d2){nv4[0], nv4[1]};
+                                        *reinterpret_cast<d2 *>(pp + 2) = (d2){nv4[2], nv4[3]};
+                                }
+                                else
+                                {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                                if (col0 + r < n)
+                                                {
+                                                        nv4[r] = pp[r] - (double)acc[u][v][r];
+                                                        pp[r] = nv4[r];
+                                                }
+                                }
+                                if (mirror || diagq)
+                                {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                                if (col0 + r < n)
+                                                        P[(size_t)(col0 + r) * NP + row] = nv4[r];
+                                }
+                        }
+        }
+}
+
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay
 /// mode also writes the pose of this callback.
 template <typename T, int MODE>
