@@ -995,13 +995,14 @@ __global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<fl
 /// the rate, and the dropped terms (2^-24 |a b| and below) are smaller than the rounding of a binary32 product chain
 /// (tools/ubench/mfma_bf16x3.hip: 6.3e-8 of sum |a b| against 1.5e-7 for an fp32 FMA chain; 294 against 149 T fp32-equivalent FLOP/s).
 /// Same tiling, tile -> workgroup map, K-loop bounds and read-modify-write epilogue as large_syrk_f32p64; the slab of V is split into its
-/// three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; rows of 80 bytes: conflict-free 16-byte reads),
+/// three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; unpadded 64-byte rows with XOR-swizzled k-groups),
 /// the operand of an MFMA is ONE 16-byte read (row l & 15, k = 8 (l >> 4) .. + 7).
 template <int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
+__global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
 {
         constexpr int TB = 128, KC = 32;
-        constexpr int LDB = KC + 8; // bf16 per LDS row: 80 bytes
+        constexpr int LDB = KC; // bf16 per LDS row: 64 bytes, unpadded; the four 16-byte k-groups of a row are XOR-swizzled with (row & 15) >> 2, which
+                                // makes the 16-byte operand reads of 16 rows conflict-free (three workgroups per CU need the 48 KB this leaves)
         typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -1052,23 +1053,27 @@ __global__ __launch_bounds__(256, 2) void large_syrk_bf16x3(DevView d, LargeView
                         tb[q] = *reinterpret_cast<const f4 *>(Bp[q] + kc);
                 }
         };
-        // four floats -> their three bf16 planes: x = h + m + l up to 2^-25 |x|
+        // four floats -> their three bf16 planes: x = h + m + l up to 2^-25 |x|.  Round to nearest at every level (v_cvt_pk_bf16_f32): with
+        // truncated pieces, which all carry the sign of x, the dropped terms a2 b3 + a3 b2 have the sign of the product, V V^T comes out
+        // systematically small and the covariance error grew 1.5x faster than with binary32 MFMAs; rounded, it is 4x smaller than theirs.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
         auto stash = [&](unsigned short (&S)[3][TB * LDB], int off, const f4 &x) {
-                unsigned h[4], m[4], l[4];
+                unsigned pk[3][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 2; ++e)
                 {
-                        // round to nearest (not truncation: truncated pieces all carry the sign of x, the dropped terms a2 b3 + a3 b2 then
-                        // have the sign of the product, and V V^T comes out systematically small: the covariance error grew 1.5x faster)
-                        const unsigned u = (__float_as_uint(x[e]) + 0x8000u) & 0xffff0000u;
-                        const float r1 = x[e] - __uint_as_float(u);
-                        const unsigned u1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
-                        const float r2 = r1 - __uint_as_float(u1);
-                        h[e] = u, m[e] = u1, l[e] = __float_as_uint(r2) + 0x8000u;
+                        const f2 v = {x[2 * e], x[2 * e + 1]};
+                        const bf2 h = __builtin_convertvector(v, bf2);
+                        const f2 r1 = v - __builtin_convertvector(h, f2);
+                        const bf2 m = __builtin_convertvector(r1, bf2);
+                        const f2 r2 = r1 - __builtin_convertvector(m, f2);
+                        const bf2 l = __builtin_convertvector(r2, bf2);
+                        pk[0][e] = __builtin_bit_cast(unsigned, h), pk[1][e] = __builtin_bit_cast(unsigned, m), pk[2][e] = __builtin_bit_cast(unsigned, l);
                 }
-                *reinterpret_cast<u2 *>(&S[0][off]) = (u2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-                *reinterpret_cast<u2 *>(&S[1][off]) = (u2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-                *reinterpret_cast<u2 *>(&S[2][off]) = (u2){(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<u2 *>(&S[p][off]) = (u2){pk[p][0], pk[p][1]};
         };
         const bool idle = (rt == jt && wc > wr); // upper quadrant of a diagonal tile: the mirror image of its lower one
         // A diagonal quadrant holds (I, J) and (J, I).  With binary32 MFMA products the two sums are bit-identical; here the six partial
@@ -1078,49 +1083,55 @@ __global__ __launch_bounds__(256, 2) void large_syrk_bf16x3(DevView d, LargeView
         const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
         const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
         const int kend = min(na, (n + KC - 1) / KC * KC); // columns n .. na-1 of V are zero (G = P H^T is zero there and L is the identity)
-        const int a_off = (wr + li) * LDB + 8 * lg, b_off = (wc + li) * LDB + 8 * lg;
+        const int a_off = (wr + li) * LDB + 8 * (lg ^ (li >> 2)), b_off = (wc + li) * LDB + 8 * (lg ^ (li >> 2)); // swizzled k-group
+        const int s_off = lrow * LDB + 8 * ((lc0 >> 3) ^ ((lrow & 15) >> 2)) + (lc0 & 4); // this thread's 8 bytes of a staged row (rows lrow + 32 q: same row & 15)
         fetch(0);
         for (int kc = 0; kc < kend; kc += KC)
         {
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q)
                 {
-                        stash(As, (lrow + RPP * q) * LDB + lc0, ta[q]);
-                        stash(Bs, (lrow + RPP * q) * LDB + lc0, tb[q]);
+                        stash(As, s_off + RPP * q * LDB, ta[q]);
+                        stash(Bs, s_off + RPP * q * LDB, tb[q]);
                 }
                 __syncthreads();
                 if (kc + KC < kend)
                         fetch(kc + KC);
-                u4 bq[4][3];
+                // two column tiles of the wave's 64x64 at a time: 24 operand registers instead of 48 (three workgroups per CU)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+                for (int vh = 0; vh < 4; vh += 2)
+                {
+                        u4 bq[2][3];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                                bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * v * LDB]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                        if (u < nu)
-                        {
-                                u4 ap[3];
+                        for (int v = 0; v < 2; ++v)
 #pragma unroll
                                 for (int p = 0; p < 3; ++p)
-                                        ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+                                        bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
 #pragma unroll
-                                for (int v = 0; v < 4; ++v)
-                                        if (v < nv && !(diagq && v > u))
-                                        {
-                                                // B x A^T (see the epilogue), small terms first
+                        for (int u = 0; u < 4; ++u)
+                                if (u < nu)
+                                {
+                                        u4 ap[3];
+#pragma unroll
+                                        for (int p = 0; p < 3; ++p)
+                                                ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+#pragma unroll
+                                        for (int v = 0; v < 2; ++v)
+                                                if (vh + v < nv && !(diagq && vh + v > u))
+                                                {
+                                                        // B x A^T (see the epilogue), small terms first
 #define ASLAM_MM(pb, pa)                                                                                               \
-        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bq[v][pb]), __builtin_bit_cast(bf8, ap[pa]), acc[u][v], 0, 0, 0)
-                                                ASLAM_MM(0, 2);
-                                                ASLAM_MM(1, 1);
-                                                ASLAM_MM(2, 0);
-                                                ASLAM_MM(0, 1);
-                                                ASLAM_MM(1, 0);
-                                                ASLAM_MM(0, 0);
+        acc[u][vh + v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bq[v][pb]), __builtin_bit_cast(bf8, ap[pa]), acc[u][vh + v], 0, 0, 0)
+                                                        ASLAM_MM(0, 2);
+                                                        ASLAM_MM(1, 1);
+                                                        ASLAM_MM(2, 0);
+                                                        ASLAM_MM(0, 1);
+                                                        ASLAM_MM(1, 0);
+                                                        ASLAM_MM(0, 0);
 #undef ASLAM_MM
-                                        }
-                        }
+                                                }
+                                }
+                }
                 __syncthreads();
         }
         if (idle)

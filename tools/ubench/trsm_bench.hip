@@ -306,6 +306,10 @@ int main(int argc, char **argv)
                             sf / (ms * 1e-3) / 1e12 / 157.3 * 100);
                 const float msk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
                 std::printf("  syrk_f32p64<32> without the read-modify-write of P  %8.3f ms\n", msk);
+                const float mb = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<0>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_bf16x3      %8.3f ms for %d filters = %6.1f T fp32-equivalent FLOP/s executed\n", mb, B, sf / (mb * 1e-3) / 1e12);
+                const float mbk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_bf16x3 without the read-modify-write of P      %8.3f ms\n", mbk);
         }
         return 0;
 }
