@@ -1128,10 +1128,10 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
         {
                 const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : c->cfg.batch >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
                 if (c->cfg.dtype == ASLAM_F32 && resident)
-                        std::snprintf(buf, sizeof(buf), "large_chol_resident + large_trsm_pipe<%d> + large_syrk_f32p64 (6-launch chain per callback, %d stream groups)",
+                        std::snprintf(buf, sizeof(buf), "large_chol_resident + large_trsm_pipe<%d> + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)",
                                       (int)LARGE_NB_MAX, c->large_groups);
                 else if (c->cfg.dtype == ASLAM_F32)
-                        std::snprintf(buf, sizeof(buf), "large_trsm_pipe<%d> + large_syrk_f32p64 (%d-launch chain per callback: multi-workgroup Cholesky)",
+                        std::snprintf(buf, sizeof(buf), "large_trsm_pipe<%d> + large_syrk_bf16x3 (%d-launch chain per callback: multi-workgroup Cholesky)",
                                       (int)LARGE_NB_MAX, 4 + 2 * (c->NP / LB));
                 else
                         std::snprintf(buf, sizeof(buf), "large_update_panel<double> (%d-launch chain per callback, %d stream groups)",

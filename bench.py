@@ -342,7 +342,11 @@ def roofline(workload, B, C, kernel_s):
                     "minimum the survey defines) x callbacks x trajectories per launch / mean launch duration (HIP events on the "
                     "launch stream); executed_frac = the same with the flops the kernels really issue (padded tiles; the single-CU EKF "
                     "update needs only S^-1 since R = r I: about n^3); peak = dense " + ("fp32" if large else "fp64")
-                    + " MFMA rate (MI355X_MICROARCH.md); traffic = PMC bytes at the L2's memory side (profiles/pmc_traffic.json)"}
+                    + " MFMA rate (MI355X_MICROARCH.md); traffic = PMC bytes at the L2's memory side (profiles/pmc_traffic.json)"
+                    + ("; the n^3 flops of P -= V V^T (of the 2.33 n^3) are binary32 products formed on the bf16 matrix pipe -- every float split "
+                       "exactly into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per 16x16x32 product, fp32 accumulation: twice the fp32 MFMA "
+                       "rate at a smaller error (tools/ubench/mfma_bf16x3.hip) -- and are counted as the fp32 flops they replace; the peak stays the "
+                       "fp32 MFMA figure the path's arithmetic type names" if large else "")}
 
 
 def main():
