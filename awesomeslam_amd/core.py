@@ -17,14 +17,14 @@ EKF, UKF = 0, 1
 F64, F32 = 0, 1
 FILTERS = {"ekf": EKF, "ukf": UKF}
 
-ST_GROWTH_REFUSED, ST_WAIT_OVERFLOW, ST_NOT_PD, ST_OBS_OVERFLOW = 1, 2, 4, 8
+ST_GROWTH_REFUSED, ST_WAIT_OVERFLOW, ST_NOT_PD, ST_OBS_OVERFLOW, ST_INTERNAL = 1, 2, 4, 8, 16
 
 # every symbol include/aslam_core.h declares (tests check the library exports them all)
 CORE_SYMBOLS = (
     "aslam_create", "aslam_destroy", "aslam_reset", "aslam_last_error", "aslam_abi_version", "aslam_set_state",
     "aslam_grow", "aslam_ekf_step", "aslam_ukf_step", "aslam_ekf_step_batch", "aslam_ukf_step_batch", "aslam_set_trace", "aslam_replay", "aslam_get_dim",
     "aslam_get_state", "aslam_get_A", "aslam_get_landmarks", "aslam_get_wait", "aslam_get_status",
-    "aslam_get_layout", "aslam_kernel_info",
+    "aslam_get_layout", "aslam_kernel_info", "aslam_get_launch_info",
 )
 NODE_SYMBOLS = (
     "aslam_node_create", "aslam_node_destroy", "aslam_node_error", "aslam_node_sensor", "aslam_node_odom",
@@ -54,18 +54,55 @@ class TraceView(ctypes.Structure):
 
 
 def build(force=False, ukf=True):
-    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU).  The Makefile scans the device assembly of the very compilation
+    that produces libaslam_core.so (tools/check_spill_exec.py, tools/check_agpr_strip.py) and moves the library into place only when
+    both guards are clean, so a library that failed one is never left where core_lib() would load it.  Writes csrc/build_info.json
+    (rebuilt or reused, compiler, time) for __graft_entry__.smoke() to print."""
+    import json
+    import time
+
+    tools = os.path.join(_CSRC, "..", "..", "tools")
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
     srcs += [os.path.join(_CSRC, "host", f) for f in os.listdir(os.path.join(_CSRC, "host"))]
-    srcs += [os.path.join(_CSRC, "Makefile"), os.path.join(_CSRC, "..", "..", "include", "aslam_core.h")]
+    srcs += [os.path.join(_CSRC, "Makefile"), os.path.join(_CSRC, "..", "..", "include", "aslam_core.h"),
+             os.path.join(tools, "check_spill_exec.py"), os.path.join(tools, "check_agpr_strip.py")]
     stale = force or not (os.path.exists(_CORE) and os.path.exists(_NODE)) or any(
         os.path.getmtime(s) > min(os.path.getmtime(_CORE), os.path.getmtime(_NODE)) for s in srcs)
+    info_path = os.path.join(_CSRC, "build_info.json")
     if stale:
         have_ukf = ukf and os.path.exists(os.path.join(_CSRC, "ukf_small.h"))
-        subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "all"])
-        # every fresh build is scanned for VGPR spill code in EXEC-empty blocks (a hipcc code-generation bug, tools/check_spill_exec.py)
-        subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "check-spills"])
+        try:
+            subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "all"])
+        except subprocess.CalledProcessError:
+            # a failed guard leaves no library behind (the Makefile builds under a temporary name); make sure of it even for a failure
+            # in a later step, so that the next build() cannot mistake an unchecked library for a fresh one
+            for f in (_CORE, _NODE):
+                if os.path.exists(f) and any(os.path.getmtime(s) > os.path.getmtime(f) for s in srcs):
+                    os.remove(f)
+            raise
+        try:
+            ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+            ver = next((ln.strip() for ln in ver.splitlines() if "HIP version" in ln), ver.strip().splitlines()[0] if ver.strip() else "?")
+        except OSError:
+            ver = "?"
+        info = {"built": time.strftime("%Y-%m-%d %H:%M:%S"), "host": os.uname().nodename, "hipcc": ver, "arch": "gfx950", "ukf": bool(have_ukf),
+                "guards": "check_spill_exec + check_agpr_strip clean on the assembly of this compilation"}
+        with open(info_path, "w") as f:
+            json.dump(info, f)
     return _CORE, _NODE
+
+
+def build_info():
+    """What build() recorded for the libraries in csrc/, plus whether THIS process found them up to date ("reused") or compiled them."""
+    import json
+
+    p = os.path.join(_CSRC, "build_info.json")
+    try:
+        info = json.load(open(p))
+    except (OSError, ValueError):
+        info = {"built": "unknown (no build_info.json: the libraries were not produced by core.build())"}
+    info["reused_here"] = info.get("host") != os.uname().nodename
+    return info
 
 
 _core = None
@@ -105,6 +142,7 @@ def core_lib():
         L.aslam_get_status.argtypes = [vp, ci, pu]
         L.aslam_get_layout.argtypes = [vp, pi, ctypes.POINTER(ctypes.c_int64)]
         L.aslam_kernel_info.argtypes = [vp, ctypes.c_char_p, ci, pi, pi, pi]
+        L.aslam_get_launch_info.argtypes = [vp, pi, pi, pi]
         _core = L
     return _core
 
@@ -414,6 +452,12 @@ class Core:
         g, b, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _chk(core_lib().aslam_kernel_info(self._h, name, 128, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
         return {"name": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    def launch_info(self):
+        """What the last replay / step of this context really launched (aslam_get_launch_info)."""
+        g, r, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _chk(core_lib().aslam_get_launch_info(self._h, ctypes.byref(g), ctypes.byref(r), ctypes.byref(l)))
+        return {"stream_groups": g.value, "chol_resident": bool(r.value), "launches_per_callback": l.value}
 
 
 class Node:

@@ -78,6 +78,10 @@ struct aslam_ctx
         static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
         hipStream_t aux[LARGE_GROUPS - 1] = {};
         hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
+        // what the LAST launch of this context really did (aslam_get_launch_info: the tests assert on it, not on the configuration)
+        int last_groups = 0;        // stream groups that received work (1 = the caller's stream alone; 0 = single-CU kernel / nothing launched yet)
+        int last_resident = 0;      // 1 = the Cholesky of S ran as large_chol_resident
+        int last_launches = 0;      // kernel launches per callback and stream group
 };
 
 namespace
@@ -306,7 +310,6 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 return g;
         };
         const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : Bz >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
-        static const bool syrk_bf16x3 = !(std::getenv("ASLAM_SYRK_BF16X3") && std::atoi(std::getenv("ASLAM_SYRK_BF16X3")) == 0); // 0: fp32 MFMA products (A/B)
         auto chain = [&](const Group &g, int s) {
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
@@ -327,10 +330,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
                         hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
-                        if (syrk_bf16x3)
-                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
-                        else
-                                hipLaunchKernelGGL(large_syrk_f32p64<32>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 else
                 {
@@ -345,6 +345,9 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                    g.dims, g.skip);
         };
         const int NG = c->large_groups;
+        c->last_resident = (sizeof(T) == 4 && resident) ? 1 : 0;
+        c->last_launches = sizeof(T) == 4 ? (resident ? 6 : 4 + 2 * NB) : 4 + 2 * NB;
+        c->last_groups = 1;
         if (MODE == MODE_STEP && sa.traj >= 0)
         {
                 Group g = make_group(sa.traj, 1, st);
@@ -367,6 +370,9 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         const int b0 = min(q * per, Bz);
                         g[q] = make_group(b0, min(per, Bz - b0), q == 0 ? st : c->aux[q - 1]);
                 }
+                c->last_groups = 0;
+                for (int q = 0; q < NG; ++q)
+                        c->last_groups += g[q].nb > 0;
                 HIP_TRY(hipEventRecord(c->ev_fork, st));
                 for (int q = 1; q < NG; ++q)
                         HIP_TRY(hipStreamWaitEvent(c->aux[q - 1], c->ev_fork, 0));
@@ -1115,6 +1121,19 @@ int aslam_scan_landmarks(const float *ranges, int64_t count, int is_device, int 
         cleanup();
         if (e != hipSuccess)
                 return fail(ASLAM_ERR_HIP, std::string("aslam_scan_landmarks: ") + hipGetErrorString(e));
+        return ASLAM_OK;
+}
+
+int aslam_get_launch_info(aslam_ctx *c, int *stream_groups, int *chol_resident, int *launches_per_callback)
+{
+        if (!c)
+                return fail(ASLAM_ERR_ARG, "null context");
+        if (stream_groups)
+                *stream_groups = c->large ? c->last_groups : 0;
+        if (chol_resident)
+                *chol_resident = c->large ? c->last_resident : 0;
+        if (launches_per_callback)
+                *launches_per_callback = c->large ? c->last_launches : 1;
         return ASLAM_OK;
 }
 

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void large_update_panel(DevView d, LargeView<T
 template <typename T>
 __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, int nfilters, const int *skipped)
 {
-        static_assert(sizeof(T) == 8, "binary32 products go through large_syrk_f32p64");
+        static_assert(sizeof(T) == 8, "binary32 products go through large_syrk_bf16x3");
         typedef Mfma<T> MM;
         constexpr int TB = 128;
         constexpr int KC = (sizeof(T) == 4) ? 32 : 16;
@@ -804,198 +804,17 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
                 }
 }
 
-/// P -= V V^T, round-2 form for binary32 products: P is stored in binary64 (the update V V^T is small against P in steady state,
-/// so rounding the UPDATE to binary32 and accumulating it into an fp64 P costs eps32 |dP| per callback instead of eps32 |P|:
-/// tools/fp32_drift_model.py), V in binary32.  Same 128x128 tiling as large_syrk (4 waves x 4x4 MFMA 16x16x4 tiles, lower tiles
-/// only, a filter's tiles on one XCD); differences:
-///   * operand fragments come out of LDS as ONE 16-byte read per four MFMAs: lane (i = l & 15, g = l >> 4) reads the four
-///     consecutive floats k = 16 c + 4 g .. + 3 of its row and uses component r in MFMA step r, i.e. the contraction index is
-///     visited in a permuted order, the same for both operands (row stride KC + 8 floats: conflict-free for ds_read_b128);
-///   * the K loop stops at the filter's size n (columns n .. of V are zero), not at the padded size;
-///   * the lower tile is read-modify-written in fp64 (16 bytes per lane and access: the products are formed as B x A^T so that a lane
-///     holds four consecutive columns of a row) and its NEW value is stored, transposed, into the upper triangle -- no read of the upper
-///     triangle, and P stays exactly symmetric.
-/// grid (8 * lower tiles * ceil(B/8)), 256 threads.
-template <int KC, int DIAG = 0>
-__global__ __launch_bounds__(256) void large_syrk_f32p64(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
-{
-        constexpr int TB = 128;
-        constexpr int LD = KC + 8;
-        __shared__ __attribute__((aligned(16))) float As[TB * LD];
-        __shared__ __attribute__((aligned(16))) float Bs[TB * LD];
-        const int ntile = (lv.NP + TB - 1) / TB, nlow = ntile * (ntile + 1) / 2;
-        const int slot = blockIdx.x >> 3;
-        const int b = (slot / nlow) * 8 + (blockIdx.x & 7);
-        if (b >= nfilters || skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
-        const int na = large_blocks(n) * LB;
-        const int tl = slot % nlow;
-        int rt = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
-        while ((rt + 1) * (rt + 2) / 2 <= tl)
-                ++rt;
-        while (rt * (rt + 1) / 2 > tl)
-                --rt;
-        const int jt = tl - rt * (rt + 1) / 2;
-        if (rt * TB >= n)
-                return;
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-        const float *G = lv.G + (size_t)b * NP * NP;
-        double *P = lv.P + (size_t)b * NP * NP;
-        // staging: KC / 4 lanes cover one row segment of a slab with 16-byte loads; 256 * 4 / KC rows per pass
-        constexpr int LPR = KC / 4, RPP = 256 / LPR, NPASS = TB / RPP;
-        const int lrow = tid / LPR, lc0 = (tid % LPR) * 4;
-        const float *Ap[NPASS], *Bp[NPASS];
-#pragma unroll
-        for (int q = 0; q < NPASS; ++q)
-        {
-                Ap[q] = G + (size_t)min(rt * TB + lrow + RPP * q, na - 1) * NP + lc0;
-                Bp[q] = G + (size_t)min(jt * TB + lrow + RPP * q, na - 1) * NP + lc0;
-        }
-        f4 acc[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                        acc[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
-        f4 ta[NPASS], tb[NPASS];
-        auto fetch = [&](int kc) {
-#pragma unroll
-                for (int q = 0; q < NPASS; ++q)
-                {
-                        ta[q] = *reinterpret_cast<const f4 *>(Ap[q] + kc);
-                        tb[q] = *reinterpret_cast<const f4 *>(Bp[q] + kc);
-                }
-        };
-        const bool idle = (rt == jt && wc > wr); // upper quadrant of a diagonal tile: the mirror image of its lower one
-        const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
-        const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
-        const bool full = (nu == 4 && nv == 4);
-        const int kend = min(na, (n + KC - 1) / KC * KC); // columns n .. na-1 of V are zero (G = P H^T is zero there and L is the identity)
-        const int a_off = (wr + li) * LD + 4 * lg, b_off = (wc + li) * LD + 4 * lg;
-        fetch(0);
-        for (int kc = 0; kc < kend; kc += KC)
-        {
-#pragma unroll
-                for (int q = 0; q < NPASS; ++q)
-                {
-                        *reinterpret_cast<f4 *>(&As[(lrow + RPP * q) * LD + lc0]) = ta[q];
-                        *reinterpret_cast<f4 *>(&Bs[(lrow + RPP * q) * LD + lc0]) = tb[q];
-                }
-                __syncthreads();
-                if (kc + KC < kend)
-                        fetch(kc + KC);
-                if (full)
-                {
-#pragma unroll
-                        for (int c = 0; c < KC / 16; ++c)
-                        {
-                                f4 av[4], bv[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u)
-                                {
-                                        av[u] = *reinterpret_cast<const f4 *>(&As[a_off + 16 * u * LD + 16 * c]);
-                                        bv[u] = *reinterpret_cast<const f4 *>(&Bs[b_off + 16 * u * LD + 16 * c]);
-                                }
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                                                for (int v = 0; v < 4; ++v)
-                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[v][r], av[u][r], acc[u][v], 0, 0, 0); // B x A^T: see the epilogue
-                        }
-                }
-                else
-                {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                                if (u < nu)
-#pragma unroll
-                                        for (int v = 0; v < 4; ++v)
-                                                if (v < nv)
-#pragma unroll
-                                                        for (int c = 0; c < KC / 16; ++c)
-                                                        {
-                                                                const f4 a4 = *reinterpret_cast<const f4 *>(&As[a_off + 16 * u * LD + 16 * c]);
-                                                                const f4 b4 = *reinterpret_cast<const f4 *>(&Bs[b_off + 16 * v * LD + 16 * c]);
-#pragma unroll
-                                                                for (int r = 0; r < 4; ++r)
-                                                                        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[r], a4[r], acc[u][v], 0, 0, 0);
-                                                        }
-                }
-                __syncthreads();
-        }
-        if (idle)
-                return;
-        if constexpr (DIAG & 1)
-        {
-                // diagnostic build only (tools/ubench/trsm_bench.hip): the K loop without the read-modify-write of P
-                float sres = 0.f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                                sres += acc[u][v][0] + acc[u][v][1] + acc[u][v][2] + acc[u][v][3];
-                if (sres == 12345.678f)
-                        P[0] = sres;
-                return;
-        }
-        const bool mirror = (jt < rt || wc < wr);
-        {
-                // The K loop multiplies B x A^T (operands swapped), so a lane's four registers are four consecutive COLUMNS of one row of the
-                // lower tile: 32 contiguous bytes, two 16-byte loads and stores per 16x16 tile; the mirror image is the strided side (four
-                // 8-byte stores).  With A x B^T (four consecutive rows per lane: four 8-byte loads + stores, 16-byte mirror stores) the
-                // epilogue cost 0.66 ms per 256 filters against 0.33 ms (trsm_bench).
-                typedef double d2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                        {
-                                const int row = rt * TB + wr + 16 * u + li;
-                                const int col0 = jt * TB + wc + 16 * v + 4 * lg;
-                                if (row >= n || col0 >= n)
-                                        continue;
-                                double *pp = P + (size_t)row * NP + col0;
-                                double nv4[4];
-                                if (col0 + 3 < n)
-                                {
-                                        const d2 o0 = *reinterpret_cast<const d2 *>(pp), o1 = *reinterpret_cast<const d2 *>(pp + 2);
-                                        nv4[0] = o0[0] - (double)acc[u][v][0], nv4[1] = o0[1] - (double)acc[u][v][1];
-                                        nv4[2] = o1[0] - (double)acc[u][v][2], nv4[3] = o1[1] - (double)acc[u][v][3];
-                                        *reinterpret_cast<d2 *>(pp) = (d2){nv4[0], nv4[1]};
-                                        *reinterpret_cast<d2 *>(pp + 2) = (d2){nv4[2], nv4[3]};
-                                }
-                                else
-                                {
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r)
-                                                if (col0 + r < n)
-                                                {
-                                                        nv4[r] = pp[r] - (double)acc[u][v][r];
-                                                        pp[r] = nv4[r];
-                                                }
-                                }
-                                if (mirror)
-                                {
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r)
-                                                if (col0 + r < n)
-                                                        P[(size_t)(col0 + r) * NP + row] = nv4[r];
-                                }
-                        }
-        }
-}
-
 /// P -= V V^T with the binary32 products formed on the BF16 matrix pipe ("bf16x3"): every float is the exact sum of three bf16 pieces of
 /// eight mantissa bits (a = a1 + a2 + a3), and  a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1):  six v_mfma_f32_16x16x32_bf16
 /// (16x16x32 per instruction, fp32 accumulation, bf16 x bf16 products exact) do the work of eight v_mfma_f32_16x16x4_f32 at twice
 /// the rate, and the dropped terms (2^-24 |a b| and below) are smaller than the rounding of a binary32 product chain
 /// (tools/ubench/mfma_bf16x3.hip: 6.3e-8 of sum |a b| against 1.5e-7 for an fp32 FMA chain; 294 against 149 T fp32-equivalent FLOP/s).
-/// Same tiling, tile -> workgroup map, K-loop bounds and read-modify-write epilogue as large_syrk_f32p64; the slab of V is split into its
-/// three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; unpadded 64-byte rows with XOR-swizzled k-groups),
+/// P is stored in binary64 (the update V V^T is small against P in steady state, so rounding the UPDATE to binary32 and accumulating it into
+/// an fp64 P costs eps32 |dP| per callback instead of eps32 |P|: tools/fp32_drift_model.py), V in binary32.  Same 128x128 tiling and tile ->
+/// workgroup map as large_syrk (4 waves x 4x4 MFMA tiles, lower tiles only, a filter's tiles on one XCD); the K loop stops at the filter's
+/// size n (columns n .. of V are zero); the lower tile is read-modify-written in fp64 (16 bytes per lane and access: the products are formed
+/// as B x A^T so that a lane holds four consecutive columns of a row) and its NEW value is stored, transposed, into the upper triangle -- no
+/// read of the upper triangle, and P stays exactly symmetric.  The slab of V is split into its three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; unpadded 64-byte rows with XOR-swizzled k-groups),
 /// the operand of an MFMA is ONE 16-byte read (row l & 15, k = 8 (l >> 4) .. + 7).
 template <int DIAG = 0>
 __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)

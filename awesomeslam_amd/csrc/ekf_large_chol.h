@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
         __shared__ unsigned sync_ctr; // the sweeps' wave synchronisation (TrsmPipe): counts on through all block rows
         if (tid == 0)
                 sync_ctr = 0;
-        unsigned nsig = 0;
+        unsigned nsig = 0, lost = 0;
         const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(Sb, 0, NP * NP * 4, 0x00020000);
         bool ok = true;
         // STAMP (diagnostic build, tools/ubench/trsm_bench.hip): shader cycles of workgroup 0 by phase -> lv.Y[0 .. 3]: sweeps, conversion, diagonal
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 f4 c[4];
                 trsm_sweep<0, true>(c, rsb, vs, I, seq, seq_diag, pp, a_off, tid);
                 nsig = pp.nsig;
+                lost |= pp.lost;
                 __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
                 ASLAM_PH(0)
                 // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle
@@ -299,5 +300,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                                 lv.Y[i] = (double)tph[i];
         if (!ok && tid == 0)
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
+        if (lost && lane == 0)
+                atomicOr(&d.status[b], 16u); // ASLAM_ST_INTERNAL: a wave gave up waiting for the others (TrsmPipe::wait)
 }
 } // namespace aslam

@@ -281,6 +281,7 @@ struct TrsmPipe
         unsigned *ctr;   // LDS word, zero at kernel start
         unsigned nsig;   // signals this wave has given
         unsigned seen;   // last value read
+        unsigned lost = 0; // set when a wait gave up (bounded spin): the kernel then raises ASLAM_ST_INTERNAL for the filter
         __device__ __forceinline__ unsigned ctr_lds() const
         {
                 typedef __attribute__((address_space(3))) unsigned lds_uint;
@@ -304,8 +305,10 @@ struct TrsmPipe
         {
                 seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         }
-        /// all four waves have given `nsig` signals; the spin is bounded (a lost signal would otherwise hang the GPU: results are then wrong, the
-        /// parity tests say so)
+        /// all four waves have given `nsig` signals; the spin is bounded (a lost signal would otherwise hang the GPU).  Giving up leaves
+        /// the LDS buffers racy, i.e. the filter's results invalid: `lost` is set and the kernels report it as the sticky status bit
+        /// ASLAM_ST_INTERNAL.  Wave-uniform by construction (scalar compares on readfirstlane values): every call site runs with EXEC == -1,
+        /// which the s_mov_b64 exec pairs of trsm_half_a_stash rely on.
         __device__ __forceinline__ void wait()
         {
                 if (__builtin_expect(seen < 4u * nsig, 0)) // wave-uniform; the usual case falls through
@@ -313,6 +316,8 @@ struct TrsmPipe
                         unsigned v = seen;
                         for (int spin = 0; v < 4u * nsig && spin < (1 << 22); ++spin)
                                 v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (v < 4u * nsig)
+                                lost = 1u;
                 }
                 asm volatile("" ::: "memory");
         }
@@ -404,6 +409,9 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], __amdgpu_buffer_rsrc_t rg
                 return (f4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
         };
         f4 pf[4], a0[4], a1[4], g0[4];
+        // From here to the end of the sweep the strip registers a0 .. a255 are live WITHOUT the compiler knowing: tools/check_agpr_strip.py
+        // (run by the build on the assembly of this very compilation) rejects any compiler-generated AGPR use between the two markers.
+        asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t)
         {
@@ -506,6 +514,7 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], __amdgpu_buffer_rsrc_t rg
                 }
                 pp.rotate();
         }
+        asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
 }
 
 /// V = G L^-T.  grid (8 * ceil(B / 8) * NP / 64), 256 threads; wave w of a workgroup owns 16 rows of G.  In place: G -> V.
@@ -545,6 +554,8 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
         TrsmPipe pp = {lds[0], lds[1], lds[2], &sync_ctr, 0u, 0u};
         f4 c[4];
         trsm_sweep<DIAG, false>(c, rg, vg, nb, seq, seq, pp, a_off, tid);
+        if (pp.lost && lane == 0)
+                atomicOr(&d.status[b], 16u); // ASLAM_ST_INTERNAL
         if constexpr (DIAG & 8)
         {
                 if (tid == 0)

@@ -80,6 +80,12 @@ class Trace:
         return Trajectory(self.odom[b], self.dt[b], self.obs_new[b], self.n_obs[b], self.obs[b],
                           self.landmarks[b], None if self.truth is None else self.truth[b], self.warmup)
 
+    def select(self, ids):
+        """The trajectories `ids` (in that order) as a trace of their own."""
+        ids = list(ids)
+        return Trace(self.odom[ids], self.dt[ids], self.obs_new[ids], self.n_obs[ids], self.obs[ids], self.landmarks[ids],
+                     None if self.truth is None else self.truth[ids], self.warmup, dict(self.meta))
+
     def save(self, path):
         np.savez_compressed(path, magic=TRACE_MAGIC, odom=self.odom, dt=self.dt, obs_new=self.obs_new,
                             n_obs=self.n_obs, obs=self.obs, landmarks=self.landmarks, truth=self.truth,

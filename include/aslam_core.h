@@ -52,7 +52,9 @@ enum
         ASLAM_ST_GROWTH_REFUSED = 1, /* updateNewLandmark hit N >= MAX_LANDMARK_COUNT (ekf.cpp:263-268): landmarks dropped */
         ASLAM_ST_WAIT_OVERFLOW = 2,  /* wait-list capacity (max_wait) exceeded: an entry was dropped (deviation!) */
         ASLAM_ST_NOT_PD = 4,         /* a Cholesky pivot was <= 0 (the reference would go on with garbage, ukf.cpp:280) */
-        ASLAM_ST_OBS_OVERFLOW = 8    /* a sensor message had more entries than max_obs */
+        ASLAM_ST_OBS_OVERFLOW = 8,   /* a sensor message had more entries than max_obs */
+        ASLAM_ST_INTERNAL = 16       /* an on-chip synchronisation of the large-state kernels timed out (bounded spin instead of a hung GPU):
+                                        this filter's state is invalid from that callback on */
 };
 
 typedef struct aslam_ctx aslam_ctx;
@@ -152,6 +154,10 @@ int aslam_get_status(aslam_ctx *ctx, int traj, uint32_t *status_bits);
 int aslam_get_layout(aslam_ctx *ctx, int *padded_dim, int64_t *hbm_bytes);
 /* name + launch geometry of the kernel aslam_replay uses for this context (for profiles / bench reports) */
 int aslam_kernel_info(aslam_ctx *ctx, char *name, int name_cap, int *grid, int *block, int *lds_bytes);
+/* what the LAST aslam_replay / aslam_*_step[_batch] of this context really launched (large-state path; the single-CU kernels report
+ * 0, 0, 1): stream groups the batch was split into (1 = the caller's stream alone), whether the Cholesky of S ran as the one-launch
+ * resident kernel, kernel launches per callback and group.  Lets a test assert that it exercised the launch shape it means to. */
+int aslam_get_launch_info(aslam_ctx *ctx, int *stream_groups, int *chol_resident, int *launches_per_callback);
 
 #ifdef __cplusplus
 }

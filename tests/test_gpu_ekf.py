@@ -280,19 +280,24 @@ def test_replay_from_trace_file_and_rostopic_dump(built, tmp_path):
     assert max(rel_err(p.cpu().numpy()[0], po), rel_err(X, Xo), cov_err(P, Po)) < REL_TOL
 
 
-@pytest.mark.parametrize("kind,n", [("ekf", 13), ("ekf", 131), ("ukf", 29), ("ekf", 203)])
-def test_batched_step_seam(kind, n, built):
+@pytest.mark.parametrize("kind,n,B,dtype", [("ekf", 13, 5, "f64"), ("ekf", 131, 5, "f64"), ("ukf", 29, 5, "f64"), ("ekf", 203, 5, "f64"),
+                                             ("ekf", 203, 40, "f64"), ("ekf", 203, 40, "f32")])
+def test_batched_step_seam(kind, n, B, dtype, built, monkeypatch):
     """aslam_ekf_step_batch / aslam_ukf_step_batch: slam() for all filters of a context in one asynchronous launch chain, against B
-    independent oracles (ekf.cpp:94,293 / ukf.cpp:90,260 called once per robot).  n = 203 goes through the large path."""
+    independent oracles (ekf.cpp:94,293 / ukf.cpp:90,260 called once per robot).  n = 203 goes through the large path; with 40 filters
+    the batched step takes the multi-stream-group branch (step_in / Linv group offsets) and, in binary32, the resident Cholesky the
+    library chooses from 32 filters on -- the shape of bench.py's pcie_step_batch leg; asserted from aslam_get_launch_info."""
     import torch
-    from awesomeslam_amd.core import Core
+    from awesomeslam_amd.core import Core, F32, F64
     from oracle.c_oracle import CFilter
-    from test_gpu_large import synth
+    from test_gpu_large import F32_SYNTH_TOL, synth
 
-    B = 5
+    monkeypatch.delenv("ASLAM_CHOL_RESIDENT", raising=False)
+    monkeypatch.delenv("ASLAM_LARGE_GROUPS", raising=False)
+    tol = REL_TOL if dtype == "f64" else F32_SYNTH_TOL  # synthetic dense covariances: the bar of test_single_slam_on_synthetic_state
     rng = np.random.default_rng(n)
     cap = max(30, n + 1)
-    core = Core(kind, cap, batch=B, max_obs=4, max_wait=4)
+    core = Core(kind, cap, batch=B, max_obs=4, max_wait=4, dtype=F32 if dtype == "f32" else F64)
     oracles = []
     Zs = np.zeros((B, n + 3))  # a row stride larger than n on purpose
     for b in range(B):
@@ -329,8 +334,14 @@ def test_batched_step_seam(kind, n, built):
             o.slam(float(vx[b]), float(az[b]), float(dt[b]))
             Xo, _, Po = o.state()
             assert np.isfinite(Po).all()
-            assert rel_err(Xout[b], Xo) < REL_TOL, (step, b)
+            assert rel_err(Xout[b], Xo) < tol, (step, b)
+    if B >= 32:
+        info = core.launch_info()
+        assert info["stream_groups"] == 3 and info["chol_resident"] == (dtype == "f32"), info
+    worst = 0.0
     for b, (o, a) in enumerate(oracles):
         Xo, _, Po = o.state()
         X, _, P = core.state(b)
-        assert rel_err(X, Xo) < REL_TOL and cov_err(P, Po) < REL_TOL and core.status(b) == 0
+        worst = max(worst, rel_err(X, Xo), cov_err(P, Po))
+        assert rel_err(X, Xo) < tol and cov_err(P, Po) < tol and core.status(b) == 0, b
+    print(f"batched step {kind} n={n} B={B} {dtype}: worst rel err X/P over the batch {worst:.2e}")

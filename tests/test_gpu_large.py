@@ -122,15 +122,17 @@ def test_replay_parity(L, T, kw, dtype, built, monkeypatch):
         assert max(errs) < tol and core.status(b) == 0
 
 
-def test_replay_parity_stream_groups(built):
-    """A batch of 19 is replayed as groups of filters on separate streams (uneven: the last group is short): trajectories
-    of every group, including the first and last of each, must match the oracle, and poses and dimensions must land in
-    the caller's buffers at the right rows"""
+def test_replay_parity_stream_groups(built, monkeypatch):
+    """A batch of 35 is replayed as groups of filters on separate streams (16 / 16 / 3: uneven, the last group short, the fourth
+    empty): trajectories of every group, including the first and last of each, must match the oracle, and poses and dimensions
+    must land in the caller's buffers at the right rows.  (Round 2 ran this with 19 filters, which stayed below the 8 x groups
+    threshold of aslam_core.hip and never left the single stream: the launch shape is now asserted, not assumed.)"""
     import torch
     from awesomeslam_amd.core import Core, F64
     from oracle.c_oracle import CFilter
 
-    L, T, B = 80, 70, 19
+    monkeypatch.delenv("ASLAM_LARGE_GROUPS", raising=False)
+    L, T, B = 80, 70, 35
     tr = tg.make_traces(L, T, B=B, seed=63)
     core = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=F64)
     core.set_trace(tr)
@@ -138,7 +140,8 @@ def test_replay_parity_stream_groups(built):
     dims = torch.zeros((B, T), dtype=torch.int32, device="cuda")
     core.replay(0, T, poses.data_ptr(), dims.data_ptr())
     torch.cuda.synchronize()
-    for b in (0, 7, 8, 15, 16, 18):
+    assert core.launch_info()["stream_groups"] == 3, core.launch_info()
+    for b in (0, 7, 15, 16, 24, 31, 32, 34):
         o = CFilter("ekf", tg.dim_cap(L))
         po, do = o.replay(tr[b])
         Xo, Zo, Po = o.state()
@@ -147,6 +150,44 @@ def test_replay_parity_stream_groups(built):
         errs = rel_err(poses.cpu().numpy()[b], po), rel_err(X, Xo), cov_err(P, Po)
         print(f"large replay groups b={b} N={core.dim(b)}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < REL_TOL and core.status(b) == 0
+
+
+def test_replay_parity_bench_launch_shape(built, monkeypatch):
+    """The launch shape bench.py times, against the oracle: binary32 products, a batch of 40 (>= 32: four stream groups of 16 / 16 / 8 / 0
+    filters with shifted views, the resident one-launch Cholesky chosen by the library itself -- ASLAM_CHOL_RESIDENT is NOT set --, filter
+    indices beyond 8 inside large_trsm_pipe / large_syrk_bf16x3 / large_chol_resident), replayed in two launches.  Trajectories at the
+    group boundaries and inside the groups are compared; the launch shape is asserted from aslam_get_launch_info."""
+    import torch
+    from awesomeslam_amd.core import Core, F32
+    from oracle.c_oracle import CFilter
+
+    monkeypatch.delenv("ASLAM_CHOL_RESIDENT", raising=False)
+    monkeypatch.delenv("ASLAM_LARGE_GROUPS", raising=False)
+    L, T, B = 80, 70, 40
+    tr = tg.make_traces(L, T, B=B, seed=65)
+    core = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=F32)
+    core.set_trace(tr)
+    half = T // 2
+    poses = torch.zeros((2, B, half, 3), dtype=torch.float64, device="cuda")
+    dims = torch.zeros((2, B, half), dtype=torch.int32, device="cuda")
+    core.replay(0, half, poses[0].data_ptr(), dims[0].data_ptr())
+    core.replay(half, T - half, poses[1].data_ptr(), dims[1].data_ptr())
+    torch.cuda.synchronize()
+    info = core.launch_info()
+    assert info["stream_groups"] == 3 and info["chol_resident"] and info["launches_per_callback"] <= 6, info
+    pg = np.concatenate([poses[0].cpu().numpy(), poses[1].cpu().numpy()], axis=1)
+    dg = np.concatenate([dims[0].cpu().numpy(), dims[1].cpu().numpy()], axis=1)
+    for b in (0, 7, 8, 15, 16, 23, 24, 31, 32, 39):
+        o = CFilter("ekf", tg.dim_cap(L))
+        po, do = o.replay(tr[b])
+        Xo, Zo, Po = o.state()
+        X, Z, P = core.state(b)
+        assert np.array_equal(dg[b], do) and np.array_equal(Z, Zo)
+        for a, c in zip(core.wait_list(b, cap=2048), o.wait_list()):
+            assert np.array_equal(a, c)
+        errs = rel_err(pg[b], po), rel_err(X, Xo), cov_err(P, Po)
+        print(f"bench launch shape f32 b={b} N={core.dim(b)}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        assert max(errs) < F32_TOL and core.status(b) == 0
 
 
 def test_config4_512_landmarks(built, monkeypatch):

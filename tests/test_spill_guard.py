@@ -43,4 +43,44 @@ def test_product_assembly_is_clean():
     csrc = os.path.join(ROOT, "awesomeslam_amd", "csrc")
     r = subprocess.run(["make", "-s", "-C", csrc, "check-spills"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
-    assert b"check_spill_exec: clean" in r.stdout
+    assert b"check_spill_exec: clean" in r.stdout and b"check_agpr_strip: clean" in r.stdout
+
+
+STRIP = """
+_ZN5aslam15large_trsm_pipeILi17ELi0EEEv:  ; @_ZN5aslam15large_trsm_pipeILi17ELi0EEEv
+	s_load_dword s0, s[4:5], 0x0
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_BEGIN
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x4_f32 v[0:3], v4, a12, v[0:3]
+	;;#ASMEND
+%s
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_END
+	;;#ASMEND
+	s_endpgm
+_ZN5aslam19large_chol_residentILi17ELi0EEEv:  ; @_ZN5aslam19large_chol_residentILi17ELi0EEEv
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_BEGIN
+	;;#ASMEND
+	v_add_f32_e32 v1, v2, v3
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_END
+	;;#ASMEND
+	v_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[6:7], 0
+	s_endpgm
+"""
+
+
+def test_agpr_strip_detector(tmp_path):
+    """compiler-generated AGPR use while the hand-allocated strip of the large-state kernels is live: flagged inside
+    the markers, accepted outside them (the fp64 MFMAs of the diagonal-block factorisation run between two sweeps)"""
+    import check_agpr_strip as g
+
+    for name, filler, want in (("ok.s", "\tv_add_f32_e32 v1, v2, v3", 0), ("spill.s", "\tv_accvgpr_write_b32 a3, v5 ;  Reload Reuse", 1),
+                               ("mfma.s", "\tv_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[6:7], 0", 1)):
+        p = tmp_path / name
+        p.write_text(STRIP % filler)
+        f = g.scan(str(p))
+        assert len(f) == want, (name, f)

@@ -1,11 +1,11 @@
 // trsm_bench.hip -- stand-alone correctness + timing harness for the kernels of the large-state EKF's binary32 chain
-// (ekf_large_trsm.h, ekf_large_chol.h, large_syrk_f32p64 in ekf_large.h), round 2.
+// (ekf_large_trsm.h, ekf_large_chol.h, large_syrk_bf16x3 in ekf_large.h), round 2.
 // Random SPD S -> host Cholesky (double) -> L and the inverses of its 64x64 diagonal blocks in binary32; random G.  Checks:
 // large_trsm_pipe's V against a host triangular solve, large_chol_resident's L and Linv against the host factor.  Timings: the product
 // kernels at several batch sizes, and diagnostic variants of large_trsm_pipe with one part of the block pipeline removed, stamped inside
 // the kernel with s_memtime / s_memrealtime (cycles per MFMA and wave).  DIAG bits of large_trsm_pipe: 1 = no global fetch of the L
 // blocks (stale LDS), 2 = no LDS stash and no synchronisation, 16 = no synchronisation (racy), 32 = every fetch reads one block (L1 hits:
-// separates the issue cost of the fetch from its latency), 8 = stamps.  large_chol_resident<17, 1>: phase stamps.  large_syrk_f32p64<32, 1>:
+// separates the issue cost of the fetch from its latency), 8 = stamps.  large_chol_resident<17, 1>: phase stamps.  large_syrk_bf16x3<1>:
 // the K loop without the read-modify-write of P.  The numbers quoted in DESIGN.md and profiles/r02_experiments.md come from this program.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I awesomeslam_amd/csrc tools/ubench/trsm_bench.hip -o /tmp/trsm_bench && /tmp/trsm_bench [filters]
 #include <hip/hip_runtime.h>
@@ -300,12 +300,8 @@ int main(int argc, char **argv)
         {
                 const int ntile = (NP + 127) / 128;
                 const dim3 grid(8 * (ntile * (ntile + 1) / 2) * ((B + 7) / 8));
-                const float ms = time_ms([&]() { hipLaunchKernelGGL(large_syrk_f32p64<32>, grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
                 const double sf = (ntile * (ntile + 1) / 2 - ntile * 0.25) * 2.0 * 128 * 128 * 1056 * B;
-                std::printf("  syrk_f32p64<32>  %8.3f ms for %d filters = %6.1f TFLOP/s executed (%4.1f %% of 157.3)\n", ms, B, sf / (ms * 1e-3) / 1e12,
-                            sf / (ms * 1e-3) / 1e12 / 157.3 * 100);
-                const float msk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_f32p64<32, 1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
-                std::printf("  syrk_f32p64<32> without the read-modify-write of P  %8.3f ms\n", msk);
+                // (round 2 also timed large_syrk_f32p64 here, the fp32-MFMA form: 3.06 ms per 256 filters, K loop 2.7 ms; removed in round 3)
                 const float mb = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<0>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
                 std::printf("  syrk_bf16x3      %8.3f ms for %d filters = %6.1f T fp32-equivalent FLOP/s executed\n", mb, B, sf / (mb * 1e-3) / 1e12);
                 const float mbk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
