@@ -75,6 +75,7 @@ struct aslam_ctx
         // chip that way, as 33 multi-workgroup launches (diagonal block + panel per block column) for few filters.
         // ASLAM_CHOL_RESIDENT=0/1 forces one form.
         int chol_resident = -1;
+        int syrk_running = 0; // diagnostic (ASLAM_SYRK_RUNNING=1): round 2's accumulation order in large_syrk_bf16x3 (profiles/r03_experiments.md)
         static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
         hipStream_t aux[LARGE_GROUPS - 1] = {};
         hipEvent_t ev_fork = nullptr, ev_join[LARGE_GROUPS - 1] = {};
@@ -330,7 +331,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
                         hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
-                        hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        if (c->syrk_running)
+                                hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        else
+                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 else
                 {
@@ -341,7 +345,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         }
                         hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
-                hipLaunchKernelGGL((large_x_update<T, MODE>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
+                hipLaunchKernelGGL((large_x_update<T, MODE, sizeof(T) == 4>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
                                    g.dims, g.skip);
         };
         const int NG = c->large_groups;
@@ -510,6 +514,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         c->large_groups = std::max(1, std::min((int)aslam_ctx::LARGE_GROUPS, std::atoi(e)));
                 if (const char *e = std::getenv("ASLAM_CHOL_RESIDENT"))
                         c->chol_resident = std::atoi(e) != 0;
+                if (const char *e = std::getenv("ASLAM_SYRK_RUNNING"))
+                        c->syrk_running = std::atoi(e) != 0;
                 for (hipStream_t &q : c->aux)
                         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
                                 rc = ASLAM_ERR_HIP;
@@ -982,6 +988,44 @@ int aslam_get_layout(aslam_ctx *c, int *padded_dim, int64_t *hbm_bytes)
         return ASLAM_OK;
 }
 
+/* diagnostic (tests/manual/large_residuals.py): the work matrices of the large path after the last callback, widened to double.
+   which: 0 = G (-> V in place) [NP][NP], 1 = S (-> L, lower block triangle) [NP][NP], 2 = Linv [17][64][64], 3 = Y [NP] */
+int aslam_debug_large(aslam_ctx *c, int traj, int which, double *out, int64_t cap)
+{
+        if (check_traj(c, traj) != ASLAM_OK)
+                return ASLAM_ERR_ARG;
+        if (!c->large || which < 0 || which > 3)
+                return fail(ASLAM_ERR_UNSUPPORTED, "aslam_debug_large: large-state contexts only");
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        const size_t NP = c->NP;
+        const size_t cnt = which < 2 ? NP * NP : which == 2 ? (size_t)LARGE_NB_MAX * LB * LB : NP;
+        if ((int64_t)cnt > cap)
+                return fail(ASLAM_ERR_ARG, "aslam_debug_large: buffer too small");
+        if (which == 3)
+        {
+                const double *src = (c->cfg.dtype == ASLAM_F32 ? c->lv32.Y : c->lv64.Y) + traj * NP;
+                HIP_TRY(hipMemcpy(out, src, cnt * sizeof(double), hipMemcpyDeviceToHost));
+                return ASLAM_OK;
+        }
+        if (c->cfg.dtype == ASLAM_F32)
+        {
+                const float *src = which == 0 ? c->lv32.G + traj * NP * NP : which == 1 ? c->lv32.S + traj * NP * NP
+                                                                                      : c->lv32.Linv + traj * cnt;
+                std::vector<float> tmp(cnt);
+                HIP_TRY(hipMemcpy(tmp.data(), src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < cnt; ++i)
+                        out[i] = (double)tmp[i];
+        }
+        else
+        {
+                const double *src = which == 0 ? c->lv64.G + traj * NP * NP : which == 1 ? c->lv64.S + traj * NP * NP
+                                                                                       : c->lv64.Linv + traj * cnt;
+                HIP_TRY(hipMemcpy(out, src, cnt * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        return ASLAM_OK;
+}
+
 #if defined(ASLAM_STAMPS) && ASLAM_HAVE_UKF
 /* diagnostic builds only: copy a UKF scratch matrix of filter `traj` to the host. which: 0 D, 1 DZ ([NP][MP]), 2 Tc, 3 K ([NP][NP]) */
 int aslam_debug_ukf(aslam_ctx *c, int traj, int which, double *out, int *rows, int *cols)
@@ -1006,6 +1050,15 @@ int aslam_debug_stamps(aslam_ctx *c, unsigned long long *out12)
         if (sync_ctx(c) != ASLAM_OK)
                 return ASLAM_ERR_HIP;
         HIP_TRY(hipMemcpy(out12, c->dv.dbg, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+/* diagnostic builds only: 100 MHz ticks spent inside large_frontend_kernel (workgroup 0) and the number of launches */
+int aslam_debug_fe_realtime(aslam_ctx *c, unsigned long long *out2)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        HIP_TRY(hipMemcpy(out2, c->dv.dbg + 56, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return ASLAM_OK;
 }
 

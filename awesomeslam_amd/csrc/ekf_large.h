@@ -164,6 +164,7 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
 #ifdef ASLAM_STAMPS
         unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+        const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz: wall time inside the kernel
 #endif
         small_load<MODE>(d, L, b, tid, NP);
         ASLAM_STAMP(0);
@@ -258,8 +259,12 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
         ASLAM_STAMP(4);
 #ifdef ASLAM_STAMPS
         if (tid == 0 && blockIdx.x == 0)
+        {
                 for (int i = 0; i < 12; ++i)
                         d.dbg[i] += stamp_acc[i];
+                d.dbg[56] += __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+                d.dbg[57] += 1;
+        }
 #endif
 }
 
@@ -901,6 +906,7 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
         const bool diagq = (rt == jt && wc == wr);
         const int nu = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (rt * TB + wr) + 15) >> 4)));
         const int nv = idle ? 0 : __builtin_amdgcn_readfirstlane(max(0, min(4, (n - (jt * TB + wc) + 15) >> 4)));
+        const bool full = !(DIAG & 2) && nu == 4 && nv == 4 && !diagq; // wave-uniform: an interior 64x64 quadrant
         const int kend = min(na, (n + KC - 1) / KC * KC); // columns n .. na-1 of V are zero (G = P H^T is zero there and L is the identity)
         const int a_off = (wr + li) * LDB + 8 * (lg ^ (li >> 2)), b_off = (wc + li) * LDB + 8 * (lg ^ (li >> 2)); // swizzled k-group
         const int s_off = lrow * LDB + 8 * ((lc0 >> 3) ^ ((lrow & 15) >> 2)) + (lc0 & 4); // this thread's 8 bytes of a staged row (rows lrow + 32 q: same row & 15)
@@ -916,41 +922,106 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                 __syncthreads();
                 if (kc + KC < kend)
                         fetch(kc + KC);
-                // two column tiles of the wave's 64x64 at a time: 24 operand registers instead of 48 (three workgroups per CU)
-#pragma unroll
-                for (int vh = 0; vh < 4; vh += 2)
+                // two column tiles of the wave's 64x64 at a time: 24 operand registers instead of 48 (three workgroups per CU).
+                // B x A^T (see the epilogue), small terms first.  The six products of a slab are summed in a ZERO-INITIALISED temporary and
+                // added to the running sum by the VALU once per slab: an MFMA that adds small products to a large accumulator truncates them
+                // (four sequential additions per instruction, each losing the addend's low bits: tools/ubench/mfma_rounding.hip), which over
+                // 198 MFMAs per element left the DIAGONAL of V V^T (sums of squares) 5.8e-7 too small -- a bias, so the covariance error grew
+                // linearly with the callbacks.  With the temporary the bias is 8e-10 and the mean error 9x smaller
+                // (tools/ubench/syrk_accum.hip).  Interior tiles (the bulk) take the branch-free path, where the addition of a pair of
+                // temporaries is issued behind the MFMAs of the NEXT pair.
+#define ASLAM_MM(t, bb, aa, c) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bb), __builtin_bit_cast(bf8, aa), c, 0, 0, 0)
+                if (full)
                 {
-                        u4 bq[2][3];
 #pragma unroll
-                        for (int v = 0; v < 2; ++v)
+                        for (int vh = 0; vh < 4; vh += 2)
+                        {
+                                u4 bq[2][3];
 #pragma unroll
-                                for (int p = 0; p < 3; ++p)
-                                        bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
+                                for (int v = 0; v < 2; ++v)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                                if (u < nu)
+                                        for (int p = 0; p < 3; ++p)
+                                                bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
+                                f4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f}; // the previous row tile's pair, not yet added
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
                                 {
                                         u4 ap[3];
 #pragma unroll
                                         for (int p = 0; p < 3; ++p)
                                                 ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
-#pragma unroll
-                                        for (int v = 0; v < 2; ++v)
-                                                if (vh + v < nv && !(diagq && vh + v > u))
-                                                {
-                                                        // B x A^T (see the epilogue), small terms first
-#define ASLAM_MM(pb, pa)                                                                                               \
-        acc[u][vh + v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bq[v][pb]), __builtin_bit_cast(bf8, ap[pa]), acc[u][vh + v], 0, 0, 0)
-                                                        ASLAM_MM(0, 2);
-                                                        ASLAM_MM(1, 1);
-                                                        ASLAM_MM(2, 0);
-                                                        ASLAM_MM(0, 1);
-                                                        ASLAM_MM(1, 0);
-                                                        ASLAM_MM(0, 0);
-#undef ASLAM_MM
-                                                }
+                                        f4 ta, tb;
+                                        ASLAM_MM(ta, bq[0][0], ap[2], ((f4){0.f, 0.f, 0.f, 0.f}));
+                                        ASLAM_MM(tb, bq[1][0], ap[2], ((f4){0.f, 0.f, 0.f, 0.f}));
+                                        ASLAM_MM(ta, bq[0][1], ap[1], ta);
+                                        ASLAM_MM(tb, bq[1][1], ap[1], tb);
+                                        ASLAM_MM(ta, bq[0][2], ap[0], ta);
+                                        ASLAM_MM(tb, bq[1][2], ap[0], tb);
+                                        if (u > 0)
+                                        {
+                                                acc[u - 1][vh] += pa;
+                                                acc[u - 1][vh + 1] += pb;
+                                        }
+                                        ASLAM_MM(ta, bq[0][0], ap[1], ta);
+                                        ASLAM_MM(tb, bq[1][0], ap[1], tb);
+                                        ASLAM_MM(ta, bq[0][1], ap[0], ta);
+                                        ASLAM_MM(tb, bq[1][1], ap[0], tb);
+                                        ASLAM_MM(ta, bq[0][0], ap[0], ta);
+                                        ASLAM_MM(tb, bq[1][0], ap[0], tb);
+                                        pa = ta, pb = tb;
+                                        __builtin_amdgcn_sched_barrier(0); // (left alone hipcc hoists every operand read of the slab to its top and spills accumulators)
                                 }
+                                acc[3][vh] += pa;
+                                acc[3][vh + 1] += pb;
+                        }
                 }
+                else
+                {
+#pragma unroll
+                        for (int vh = 0; vh < 4; vh += 2)
+                        {
+                                u4 bq[2][3];
+#pragma unroll
+                                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                                        for (int p = 0; p < 3; ++p)
+                                                bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                        if (u < nu)
+                                        {
+                                                u4 ap[3];
+#pragma unroll
+                                                for (int p = 0; p < 3; ++p)
+                                                        ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+#pragma unroll
+                                                for (int v = 0; v < 2; ++v)
+                                                        if (vh + v < nv && !(diagq && vh + v > u))
+                                                        {
+                                                                f4 tmp;
+                                                                if constexpr (DIAG & 2) // diagnostic build only (trsm_bench): round 2's running accumulator
+                                                                {
+                                                                        ASLAM_MM(tmp, bq[v][0], ap[2], acc[u][vh + v]);
+                                                                        ASLAM_MM(tmp, bq[v][1], ap[1], tmp);
+                                                                        ASLAM_MM(tmp, bq[v][2], ap[0], tmp);
+                                                                        ASLAM_MM(tmp, bq[v][0], ap[1], tmp);
+                                                                        ASLAM_MM(tmp, bq[v][1], ap[0], tmp);
+                                                                        ASLAM_MM(tmp, bq[v][0], ap[0], tmp);
+                                                                        acc[u][vh + v] = tmp;
+                                                                        continue;
+                                                                }
+                                                                ASLAM_MM(tmp, bq[v][0], ap[2], ((f4){0.f, 0.f, 0.f, 0.f}));
+                                                                ASLAM_MM(tmp, bq[v][1], ap[1], tmp);
+                                                                ASLAM_MM(tmp, bq[v][2], ap[0], tmp);
+                                                                ASLAM_MM(tmp, bq[v][0], ap[1], tmp);
+                                                                ASLAM_MM(tmp, bq[v][1], ap[0], tmp);
+                                                                ASLAM_MM(tmp, bq[v][0], ap[0], tmp);
+                                                                acc[u][vh + v] += tmp;
+                                                        }
+                                        }
+                        }
+                }
+#undef ASLAM_MM
                 __syncthreads();
         }
         if (idle)
@@ -969,6 +1040,15 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                 return;
         }
         const bool mirror = (jt < rt || wc < wr);
+        // The DIAGONAL of V V^T and its three POSE columns are formed with binary64 accumulation by large_x_update<.., SLIM> (see there) and are left
+        // alone here: the pose columns by clearing their sums (columns 0..2 = registers 0..2 of lane group 0 in the first column tile of tile
+        // column 0: the read-modify-write below then stores the old values back), the diagonal by skipping it.
+        if (jt == 0 && wc == 0 && lg == 0)
+        {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                        acc[u][0][0] = acc[u][0][1] = acc[u][0][2] = 0.f;
+        }
         {
                 // The K loop multiplies B x A^T (operands swapped), so a lane's four registers are four consecutive COLUMNS of one row of the
                 // lower tile: 32 contiguous bytes, two 16-byte loads and stores per 16x16 tile; the mirror image is the strided side (four
@@ -986,16 +1066,15 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                                         continue;
                                 if (diagq && v == u)
                                 {
-                                        // 16x16 tile on the diagonal: the elements J <= I, each with its mirror image
+                                        // 16x16 tile on the diagonal: the elements J < I, each with its mirror image (J == I: large_x_update)
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
-                                                if (col0 + r <= row)
+                                                if (col0 + r < row)
                                                 {
                                                         double *pe = P + (size_t)row * NP + col0 + r;
                                                         const double pn = *pe - (double)acc[u][v][r];
                                                         *pe = pn;
-                                                        if (col0 + r < row)
-                                                                P[(size_t)(col0 + r) * NP + row] = pn;
+                                                        P[(size_t)(col0 + r) * NP + row] = pn;
                                                 }
                                         continue;
                                 }
@@ -1032,7 +1111,13 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
 
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay
 /// mode also writes the pose of this callback.
-template <typename T, int MODE>
+///
+/// binary32 chain (SLIM): the same pass over row a of V also forms, with binary64 accumulation, the entries of V V^T that large_syrk_bf16x3
+/// leaves out -- the DIAGONAL (a sum of squares: every rounding of an fp32 accumulator chain pulls it the same way, and the covariance
+/// diagonal is where the error of the fp32 path was largest) and the three POSE columns (the pose block changes by as much as it holds in
+/// every callback, Q against the update, so eps32 |dP| is eps32 |P| there) -- and subtracts them from P: P(a,a), P(a,0..2) and the mirror
+/// image P(0..2,a).  Costs four more FMAs per element of a row the kernel reads anyway.
+template <typename T, int MODE, bool SLIM = false>
 __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv, int s, int nsteps, double *poses_out,
                                                       int32_t *dims_out, const int *skipped)
 {
@@ -1049,12 +1134,58 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
         // 16 bytes per lane and load (rows are 256-byte aligned: NP is a multiple of 64); columns n .. of both rows are zero
         typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
         constexpr int VW = 16 / sizeof(T);
-        for (int j = VW * lane; j < n; j += 64 * VW)
+        if constexpr (SLIM)
         {
-                const vec_t v = *reinterpret_cast<const vec_t *>(vrow + j), w = *reinterpret_cast<const vec_t *>(q + j);
+                const T *p0 = lv.G + (size_t)b * NP * NP, *p1 = p0 + NP, *p2 = p1 + NP;
+                double dd = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+                for (int j = VW * lane; j < n; j += 64 * VW)
+                {
+                        const vec_t v = *reinterpret_cast<const vec_t *>(vrow + j), w = *reinterpret_cast<const vec_t *>(q + j);
+                        const vec_t u0 = *reinterpret_cast<const vec_t *>(p0 + j), u1 = *reinterpret_cast<const vec_t *>(p1 + j),
+                                    u2 = *reinterpret_cast<const vec_t *>(p2 + j);
 #pragma unroll
-                for (int e = 0; e < VW; ++e)
-                        acc = fma((double)v[e], (double)w[e], acc);
+                        for (int e = 0; e < VW; ++e)
+                        {
+                                const double ve = (double)v[e];
+                                acc = fma(ve, (double)w[e], acc);
+                                dd = fma(ve, ve, dd);
+                                d0 = fma(ve, (double)u0[e], d0);
+                                d1 = fma(ve, (double)u1[e], d1);
+                                d2 = fma(ve, (double)u2[e], d2);
+                        }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1)
+                {
+                        dd += __shfl_xor(dd, off);
+                        d0 += __shfl_xor(d0, off);
+                        d1 += __shfl_xor(d1, off);
+                        d2 += __shfl_xor(d2, off);
+                }
+                if (lane == 0)
+                {
+                        double *P = lv.P + (size_t)b * NP * NP;
+                        double *prow = P + (size_t)a * NP;
+                        const double dp[3] = {d0, d1, d2};
+                        // pose columns j < min(a, 3) with their mirror image; the diagonal entry itself (a < 3: dd == dp[a] bit for bit)
+                        for (int j = 0; j < 3 && j < a; ++j)
+                        {
+                                const double pn = prow[j] - dp[j];
+                                prow[j] = pn;
+                                P[(size_t)j * NP + a] = pn;
+                        }
+                        prow[a] -= dd;
+                }
+        }
+        else
+        {
+                for (int j = VW * lane; j < n; j += 64 * VW)
+                {
+                        const vec_t v = *reinterpret_cast<const vec_t *>(vrow + j), w = *reinterpret_cast<const vec_t *>(q + j);
+#pragma unroll
+                        for (int e = 0; e < VW; ++e)
+                                acc = fma((double)v[e], (double)w[e], acc);
+                }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)

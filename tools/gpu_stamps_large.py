@@ -6,14 +6,18 @@ ac._CORE = ac._CORE.replace('libaslam_core.so','libaslam_core_stamps.so')
 import awesomeslam_amd.trace as tg
 from awesomeslam_amd.core import Core
 NAMES=['small_load','small_frontend','X, Hc, Y','P predict','small_store']
-L,B=512,8
+L,B=512,int(sys.argv[1]) if len(sys.argv)>1 else 8
 tr=tg.make_traces(L,80,B=B,seed=1)
 core=Core('ekf',tg.dim_cap(L),batch=B,max_obs=tr.max_obs,max_wait=2048,dtype=ac.F32)
 core.set_trace(tr)
 core.replay(0,60); torch.cuda.synchronize()
 lib=ac.core_lib()
 a=(ctypes.c_ulonglong*12)(); lib.aslam_debug_stamps(core._h,a); base=np.array(list(a),dtype=np.float64)
-core.replay(60,20); torch.cuda.synchronize()
+r=(ctypes.c_ulonglong*2)(); lib.aslam_debug_fe_realtime(core._h,r); rbase=np.array(list(r),dtype=np.float64)
+e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True); e0.record()
+core.replay(60,20,None,None,torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()
+lib.aslam_debug_fe_realtime(core._h,r); rr=np.array(list(r),dtype=np.float64)-rbase
+print('B=%d: 20 callbacks %.3f ms by events; front-end kernel, workgroup 0: %.1f us per launch by s_memrealtime (%d launches)'%(B,e0.elapsed_time(e1),rr[0]/100.0/max(rr[1],1),rr[1]))
 lib.aslam_debug_stamps(core._h,a); cyc=(np.array(list(a),dtype=np.float64)-base)/20
 print('large frontend cycles/callback (workgroup 0): total %.0f'%cyc.sum())
 for nm,c in zip(NAMES,cyc): print(f'   {nm:16s} {c:9.0f}')

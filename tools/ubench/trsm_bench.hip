@@ -306,6 +306,9 @@ int main(int argc, char **argv)
                 std::printf("  syrk_bf16x3      %8.3f ms for %d filters = %6.1f T fp32-equivalent FLOP/s executed\n", mb, B, sf / (mb * 1e-3) / 1e12);
                 const float mbk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
                 std::printf("  syrk_bf16x3 without the read-modify-write of P      %8.3f ms\n", mbk);
+                const float mb2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<2>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                const float mbk2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<3>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                std::printf("  syrk_bf16x3 with round 2's running accumulator (no per-slab temporaries)  %8.3f ms, without the read-modify-write %8.3f ms\n", mb2, mbk2);
         }
         return 0;
 }
