@@ -1207,3 +1207,4 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
 
 #include "ekf_large_trsm.h"
 #include "ekf_large_chol.h"
+#include "ekf_large_trsm16.h"

@@ -1,0 +1,540 @@
+// ekf_large_trsm16.h -- V = G L^-T (and the block rows of the Cholesky factor of S) with the binary32 products formed on the BF16 matrix
+// pipe (round 3).  Same recurrence and the same register-resident strip as ekf_large_trsm.h:
+//      V(i, k) = ( G(i, k) - sum_{j<k} V(i, j) L(k, j)^T ) Linv_k^T
+// a wave owns 16 rows and keeps their solved strip, TRANSPOSED, as binary32 accumulator tiles in AGPRs a0 .. a255 (tile T = a[4T .. 4T+3],
+// register r of lane l = V[row l & 15][16 T + 4 (l >> 4) + r]).  What changes is the product: every float is the sum of three bf16 pieces
+// (a = a1 + a2 + a3, round to nearest at every level) and a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1): six
+// v_mfma_f32_16x16x32_bf16 (16 cycles each) per 16x16x32 product in place of eight v_mfma_f32_16x16x4_f32 (32 cycles each) -- a 64x64
+// history block costs 48 MFMAs = 768 cycles of matrix pipe instead of 64 = 2048, at a smaller error (tools/ubench/mfma_bf16x3.hip).
+//
+//   * The blocks of L arrive ALREADY SPLIT: the kernels that produce L (large_chol_bf16, or large_split_planes for the multi-workgroup chain)
+//     write three bf16 planes per block with the columns permuted so that the A operand of an MFMA -- row l & 15 of the block, the eight
+//     contraction slots of lane group l >> 4 -- is ONE 16-byte LDS read: position 32 h + 8 g + 4 w + r holds column 32 h + 16 w + 4 g + r
+//     (h = half of the block, g = lane group, w = which of the two strip tiles of the half, r = register).
+//   * The B operand is the strip: the eight contraction slots of a lane are its OWN four registers of two consecutive strip tiles, read from the
+//     AGPRs and split by the VALU (8 v_accvgpr_read + 44 VALU per 16x32 operand, serving the 24 MFMAs of a half block): no value crosses lanes.
+//   * Accumulation: a block sums its 48 MFMAs in accumulators that start at zero and the VALU adds the block's sums to the column's running sum
+//     -- an MFMA truncates small addends it adds to a large accumulator (tools/ubench/mfma_rounding.hip); running sums over a whole block
+//     column were the source of the round-2 bias.
+// Everything except the strip accesses is plain HIP (builtins): with the B operand in VGPRs the MFMAs no longer name AGPRs, and the
+// compiler schedules MFMAs, conversions and LDS reads (sched_group_barrier pins the interleave).
+#pragma once
+
+namespace aslam
+{
+namespace t16
+{
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// A staged block in LDS: three planes of 64 unpadded 128-byte rows (the blocks arrive by LDS-DMA, which writes 1 KiB = eight whole rows per
+// wave-instruction, lane l at byte 16 l: rows cannot be padded).  The eight 16-byte chunks of row r are XOR-swizzled with r & 7 -- applied on the
+// SOURCE side of the DMA (lane l fetches the chunk that belongs at its place) and in the operand reads -- so that the 16 rows of an operand read
+// spread over all eight chunk positions (2-way conflicts instead of 16-way).
+constexpr int PLD = LB;           // bf16 per LDS row
+constexpr int PLANE = LB * PLD;   // elements of one plane of a staged block
+constexpr int BLK = 3 * PLANE;    // a staged block: three planes, 24 576 bytes
+constexpr int NBUF = 4;           // LDS buffers: block i multiplied, i + 1 complete, i + 2 / i + 3 in flight
+
+/// position of column c (0 .. 63) of a block inside a permuted plane row
+__host__ __device__ __forceinline__ int perm_pos(int c)
+{
+        return 32 * (c >> 5) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1) + (c & 3);
+}
+
+/// Planes of one filter's L in HBM.  Lq: [3][NP][NP] bf16, row-major, columns permuted inside every 64-block (only blocks below the diagonal
+/// are read); Liq: [LARGE_NB_MAX][3][64][64] bf16, the inverses of the diagonal blocks, columns permuted the same way.
+struct Planes
+{
+        unsigned short *Lq;
+        unsigned short *Liq;
+};
+
+/// two floats -> the three bf16 pieces of each, packed (lo = first): round to nearest even at every level
+__device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+        const f2v v = {a, b};
+        const bf2 hh = __builtin_convertvector(v, bf2);
+        h = __builtin_bit_cast(unsigned, hh);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const bf2 mm = __builtin_convertvector((f2v){ra, rb}, bf2);
+        m = __builtin_bit_cast(unsigned, mm);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        const bf2 ll = __builtin_convertvector((f2v){sa, sb}, bf2);
+        l = __builtin_bit_cast(unsigned, ll);
+}
+
+/// eight floats (the contraction slots of this lane, in slot order) -> three packed operands
+__device__ __forceinline__ void split8(const float (&x)[8], u4v &h, u4v &m, u4v &l)
+{
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+                unsigned hh, mm, ll;
+                split2(x[2 * e], x[2 * e + 1], hh, mm, ll);
+                h[e] = hh, m[e] = mm, l[e] = ll;
+        }
+}
+
+/// strip registers a[R0 .. R0+7] -> x (two consecutive tiles: the eight contraction slots of a half block)
+template <int R0> __device__ __forceinline__ void strip_read8(float (&x)[8])
+{
+        static_assert(R0 >= 0 && R0 + 7 < 256, "strip register");
+        asm volatile("v_accvgpr_read_b32 %0, a%c8\n\tv_accvgpr_read_b32 %1, a%c9\n\tv_accvgpr_read_b32 %2, a%c10\n\tv_accvgpr_read_b32 %3, a%c11\n\t"
+                     "v_accvgpr_read_b32 %4, a%c12\n\tv_accvgpr_read_b32 %5, a%c13\n\tv_accvgpr_read_b32 %6, a%c14\n\tv_accvgpr_read_b32 %7, a%c15\n\t"
+                     "s_nop 1"
+                     : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7])
+                     : "n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 5), "n"(R0 + 6), "n"(R0 + 7));
+}
+
+/// x (four tiles of a solved block column, accumulator layout) -> strip registers a[16 K .. 16 K + 15]
+template <int K> __device__ __forceinline__ void strip_write16(const f4 (&x)[4])
+{
+        asm volatile("v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\tv_accvgpr_write_b32 a%c11, %3\n\t"
+                     "v_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\tv_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7"
+                     :
+                     : "v"(x[0][0]), "v"(x[0][1]), "v"(x[0][2]), "v"(x[0][3]), "v"(x[1][0]), "v"(x[1][1]), "v"(x[1][2]), "v"(x[1][3]),
+                       "n"(16 * K), "n"(16 * K + 1), "n"(16 * K + 2), "n"(16 * K + 3), "n"(16 * K + 4), "n"(16 * K + 5), "n"(16 * K + 6),
+                       "n"(16 * K + 7));
+        asm volatile("v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\tv_accvgpr_write_b32 a%c11, %3\n\t"
+                     "v_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\tv_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7\n\t"
+                     "s_nop 3"
+                     :
+                     : "v"(x[2][0]), "v"(x[2][1]), "v"(x[2][2]), "v"(x[2][3]), "v"(x[3][0]), "v"(x[3][1]), "v"(x[3][2]), "v"(x[3][3]),
+                       "n"(16 * K + 8), "n"(16 * K + 9), "n"(16 * K + 10), "n"(16 * K + 11), "n"(16 * K + 12), "n"(16 * K + 13),
+                       "n"(16 * K + 14), "n"(16 * K + 15));
+}
+
+__device__ __forceinline__ f4 mm(const u4v &a, const u4v &b, const f4 &c)
+{
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+/// the operands of one half block (32 of its 64 columns): A = the rows of the staged block (four row tiles x three planes, one 16-byte LDS read
+/// each), B = the three pieces of this lane's eight contraction slots
+struct Ops
+{
+        u4v A[4][3];
+        u4v bh, bm, bl;
+};
+
+/// this lane's operand rows of half h: row 16 t + li, chunk (4 h + lg) ^ (li & 7), planes 0 .. 2.  a_row = li * PLD (elements)
+template <int T0 = 0> __device__ __forceinline__ void load_frags(u4v (&A)[4][3], const unsigned short *buf, int a_h)
+{
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                        A[t][p] = *reinterpret_cast<const u4v *>(buf + a_h + 16 * t * PLD + p * PLANE);
+}
+
+/// acc[t] (+)= block rows 16 t .. 16 t + 15 (half h) x operand, t = T0 .. 3; FIRST: acc[t] starts here (accumulator operand 0).  The six
+/// products of a tile are a dependent chain; consecutive MFMAs belong to different row tiles.
+template <bool FIRST, int T0 = 0> __device__ __forceinline__ void mfmas(f4 (&acc)[4], const Ops &o)
+{
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][0], o.bl, FIRST ? (f4){0.f, 0.f, 0.f, 0.f} : acc[t]); // small terms first
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][1], o.bm, acc[t]);
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][2], o.bh, acc[t]);
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][0], o.bm, acc[t]);
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][1], o.bh, acc[t]);
+#pragma unroll
+        for (int t = T0; t < 4; ++t)
+                acc[t] = mm(o.A[t][0], o.bh, acc[t]);
+}
+
+/// scheduling hints for a region of NM MFMAs that carries the next half's conversion and LDS reads: 1 MFMA, 2 VALU, and an LDS read every other gap
+template <int NM> __device__ __forceinline__ void interleave()
+{
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+        {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
+                if (i % 2 == 0)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+        }
+}
+
+/// One block's LDS-DMA descriptor: the regions issue its six one-KiB pieces per wave (piece i: plane i >> 1, rows 8 (4 (i & 1) + wave) .. + 7 of the
+/// block; lane l = row l >> 3 of the piece, the 16 bytes that belong at chunk position l & 7 of that row: logical chunk (l & 7) ^ (l >> 3))
+struct Dma
+{
+        __amdgpu_buffer_rsrc_t rsrc; // the filter's planes of L, or of the inverses of its diagonal blocks
+        unsigned voff;               // this lane's byte offset inside a piece
+        unsigned so[6];              // byte offsets of the six pieces
+};
+
+/// cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ... (as TrsmSeq) on the planes.  Scalar state only.
+struct Seq
+{
+        int k, j, nb, NP, wave;
+        __amdgpu_buffer_rsrc_t rl, ri;
+        unsigned vo_l, vo_i;
+        __device__ __forceinline__ Seq(const unsigned short *Lq, const unsigned short *Liq, int k0, int nb_, int NP_, int tid)
+            : k(k0), j(0), nb(nb_), NP(NP_), wave(__builtin_amdgcn_readfirstlane(tid >> 6)),
+              rl(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Lq), 0, 3 * NP_ * NP_ * 2, 0x00020000)),
+              ri(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Liq), 0, LARGE_NB_MAX * 3 * LB * LB * 2, 0x00020000))
+        {
+                const int l = tid & 63, r = l >> 3, lc = (l & 7) ^ r;
+                vo_l = (unsigned)((r * NP_ + 8 * lc) * 2);
+                vo_i = (unsigned)((r * LB + 8 * lc) * 2);
+        }
+        /// the next block of the sequence
+        __device__ __forceinline__ Dma next()
+        {
+                const bool hist = j < k;
+                Dma dm;
+                dm.rsrc = hist ? rl : ri;
+                dm.voff = hist ? vo_l : vo_i;
+                const unsigned base = hist ? (unsigned)(((LB * k) * NP + LB * j) * 2) : (unsigned)(k * 3 * LB * LB * 2);
+                const unsigned ps = hist ? (unsigned)(NP * NP * 2) : (unsigned)(LB * LB * 2), r8 = hist ? (unsigned)(8 * NP * 2) : (unsigned)(8 * LB * 2);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                        dm.so[i] = base + (unsigned)(i >> 1) * ps + (unsigned)(4 * (i & 1) + wave) * r8;
+                const bool adv = !hist && k + 1 < nb;
+                j = hist ? j + 1 : (adv ? 0 : j);
+                k += adv ? 1 : 0;
+                return dm;
+        }
+        /// outside the regions (the start of the pipeline): all six pieces of the next block -> LDS buffer `dst`
+        __device__ __forceinline__ void issue(unsigned short *dst)
+        {
+                typedef __attribute__((address_space(3))) unsigned short lds_us;
+                const Dma dm = next();
+                const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)dst + (unsigned)wave * 1024u;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                                     :
+                                     : "s"(ldsw), "n"((i >> 1) * 8192 + (i & 1) * 4096), "v"(dm.voff), "s"(dm.rsrc), "s"(dm.so[i])
+                                     : "m0", "scc", "memory");
+        }
+};
+
+/// Block pipeline over FOUR LDS buffers fed by LDS-DMA: block i is multiplied out of b0, block i + 1 is complete in b1 (its first operand rows are
+/// read behind the last MFMAs of block i), blocks i + 2 and i + 3 are in flight: the six pieces a wave moves of block i + 3 are issued INSIDE the
+/// regions of block i, between their MFMAs (issued together the 24 KB of a block keep the CU's one address unit busy for ~ 400 - 600 cycles), into
+/// the buffer block i - 1 left at the last barrier.  End of a block: every wave waits until at most the twelve youngest of its DMA pieces are
+/// outstanding -- its pieces of block i + 1 have landed (loads complete in order; a stricter count never hurts) -- and the barrier publishes block i + 1.
+struct Pipe
+{
+        unsigned short *b0, *b1, *b2, *b3;
+        // diagnostic builds (STAMP): shader cycles by phase -- 0 first-half region, 1 between the halves, 2 second-half region, 3 end (barrier), 4 closing block
+        unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+        template <int STAMP> __device__ __forceinline__ void stamp(int i)
+        {
+                if constexpr (STAMP)
+                {
+                        unsigned long long t;
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                        ph[i] += t - tlast;
+                        tlast = t;
+                }
+        }
+        /// LATER: loads issued after this wave's pieces of block i + 1 (two blocks' pieces = 12; 16 in the closing block and in the block after it, which
+        /// have the four loads of the next slice of G in between; the stores of V only make the wait stricter)
+        template <int LATER = 12> __device__ __forceinline__ void end()
+        {
+                static_assert(LATER == 12 || LATER == 16, "vmcnt count");
+                if constexpr (LATER == 12)
+                        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+                else
+                        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                unsigned short *t = b0;
+                b0 = b1;
+                b1 = b2;
+                b2 = b3;
+                b3 = t;
+        }
+};
+
+#include "ekf_large_trsm16_regions.inc"
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u16v __attribute__((ext_vector_type(16)));
+
+/// Everything the hand-scheduled regions (tools/gen_trsm16_regions.py) keep in fixed physical registers.  P / Q: the two operand sets (a region
+/// consumes one and fills the other: A = operand rows of the staged block, one 16-register tuple per plane, row tile t in registers 4 t .. 4 t + 3;
+/// bh / bm / bl = the pieces of the B operand); e / o: the block-local sums of the even / odd history blocks; run: the column's running sum.
+struct Regs
+{
+        u16v PA0, PA1, PA2, QA0, QA1, QA2;
+        u4v Pbh, Pbm, Pbl, Qbh, Qbm, Qbl;
+        f16v e, o, run;
+};
+
+#define ASLAM_T16_SCRATCH "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "m0", "scc", "memory"
+#define ASLAM_T16_Q_OUT "=&{v[160:175]}"(R.QA0), "=&{v[176:191]}"(R.QA1), "=&{v[192:207]}"(R.QA2), "=&{v[208:211]}"(R.Qbh), "=&{v[212:215]}"(R.Qbm), "=&{v[216:219]}"(R.Qbl)
+#define ASLAM_T16_P_OUT "=&{v[96:111]}"(R.PA0), "=&{v[112:127]}"(R.PA1), "=&{v[128:143]}"(R.PA2), "=&{v[144:147]}"(R.Pbh), "=&{v[148:151]}"(R.Pbm), "=&{v[152:155]}"(R.Pbl)
+#define ASLAM_T16_P_IN "{v[96:111]}"(R.PA0), "{v[112:127]}"(R.PA1), "{v[128:143]}"(R.PA2), "{v[144:147]}"(R.Pbh), "{v[148:151]}"(R.Pbm), "{v[152:155]}"(R.Pbl)
+#define ASLAM_T16_Q_IN "{v[160:175]}"(R.QA0), "{v[176:191]}"(R.QA1), "{v[192:207]}"(R.QA2), "{v[208:211]}"(R.Qbh), "{v[212:215]}"(R.Qbm), "{v[216:219]}"(R.Qbl)
+/// operands every region takes: the LDS address of the operand rows it reads, the bf16 mask, the first strip register of the B operand it prepares,
+/// and the LDS-DMA pieces it issues (pieces H .. H + 2 of descriptor dm into the buffer at LDS address ldsw)
+#define ASLAM_T16_COMMON(addr, R0, H) [lds] "v"(addr), [msk] "s"(0xffff0000u), [r0] "n"(R0), [ldsw] "s"(ldsw), [voff] "v"(dm.voff), [rsrc] "s"(dm.rsrc), [so0] "s"(dm.so[H]), [so1] "s"(dm.so[H + 1]), [so2] "s"(dm.so[H + 2])
+
+/// One history block J (even J: sums in R.e, odd J: in R.o), set P holding the operands of its first half on entry and of the NEXT block's first half
+/// on exit.  Inside the MFMA gaps of the first half: the strip registers of the second half are read and split, its operand rows are read from LDS
+/// (-> set Q), and the finished sums of the previous block are added to the column's running sum; inside those of the second half: the same for the
+/// first half of the next block in the stream (history block J + 1 of this column, whose operand rows are in b1 -- or the closing block, whose B
+/// operand is not a strip tile: that split is wasted).  Both halves carry three of the six DMA pieces of the block three ahead.
+template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &R, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
+{
+        typedef __attribute__((address_space(3))) unsigned short lds_us;
+        const Dma dm = seq.next();
+        const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u;
+        const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1); // the second half of this block
+        if constexpr (J == 0)
+                asm volatile(ASLAM_T16_H0_E : "=&{v[32:47]}"(R.e), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 16 * J + 8, 0) : ASLAM_T16_SCRATCH);
+        else if constexpr (J % 2 == 0)
+                asm volatile(ASLAM_T16_H0_E_ADD
+                             : "=&{v[32:47]}"(R.e), "+{v[64:79]}"(R.run), ASLAM_T16_Q_OUT
+                             : ASLAM_T16_P_IN, "{v[48:63]}"(R.o), ASLAM_T16_COMMON(a_cur, 16 * J + 8, 0)
+                             : ASLAM_T16_SCRATCH);
+        else
+                asm volatile(ASLAM_T16_H0_O_ADD
+                             : "=&{v[48:63]}"(R.o), "+{v[64:79]}"(R.run), ASLAM_T16_Q_OUT
+                             : ASLAM_T16_P_IN, "{v[32:47]}"(R.e), ASLAM_T16_COMMON(a_cur, 16 * J + 8, 0)
+                             : ASLAM_T16_SCRATCH);
+        pp.template stamp<STAMP>(0);
+        const unsigned a_nxt = (unsigned)(uintptr_t)(lds_us *)(pp.b1 + a_h0); // the first half of the next block
+        constexpr int RN = (J + 1 < LARGE_NB_MAX - 1) ? 16 * (J + 1) : 0;
+        pp.template stamp<STAMP>(1);
+        if constexpr (STAMP == 2)
+                asm volatile(ASLAM_T16_H1_E_NOVALU : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        else if constexpr (STAMP == 3)
+                asm volatile(ASLAM_T16_H1_E_NODS : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        else if constexpr (STAMP == 4)
+                asm volatile(ASLAM_T16_H1_E_BARE : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        else if constexpr (J % 2 == 0)
+                asm volatile(ASLAM_T16_H1_E : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        else
+                asm volatile(ASLAM_T16_H1_O : "+{v[48:63]}"(R.o), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        pp.template stamp<STAMP>(2);
+        pp.template end<(J == 0) ? 16 : 12>();
+        pp.template stamp<STAMP>(3);
+}
+
+template <int J, int STAMP> __device__ __forceinline__ void chain(Regs &R, int k, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
+{
+        if (J < k)
+        {
+                history_block<J, STAMP>(R, pp, seq, a_h0, a_h1, tid);
+                if constexpr (J + 1 < LARGE_NB_MAX - 1)
+                        chain<J + 1, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
+        }
+}
+
+/// tile t of a 16-register tuple
+template <typename V16> __device__ __forceinline__ auto tile4(const V16 &v, int t)
+{
+        typedef decltype(v[0] + v[0]) E;
+        typedef E v4 __attribute__((ext_vector_type(4)));
+        return t == 0   ? (v4){v[0], v[1], v[2], v[3]}
+               : t == 1 ? (v4){v[4], v[5], v[6], v[7]}
+               : t == 2 ? (v4){v[8], v[9], v[10], v[11]}
+                        : (v4){v[12], v[13], v[14], v[15]};
+}
+
+__device__ __forceinline__ void load_planes(u16v &A0, u16v &A1, u16v &A2, const unsigned short *buf, int a_h)
+{
+        u4v A[4][3];
+        load_frags(A, buf, a_h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                        A0[4 * t + r] = A[t][0][r], A1[4 * t + r] = A[t][1][r], A2[4 * t + r] = A[t][2][r];
+}
+
+/// c (four tiles, accumulator layout: c[t][r] = column 16 t + 4 lg + r of row li) -> the operand of half h
+__device__ __forceinline__ void split_c(const f4 (&c)[4], int h, u4v &bh, u4v &bm, u4v &bl)
+{
+        const float x[8] = {c[2 * h][0], c[2 * h][1], c[2 * h][2], c[2 * h][3], c[2 * h + 1][0], c[2 * h + 1][1], c[2 * h + 1][2], c[2 * h + 1][3]};
+        split8(x, bh, bm, bl);
+}
+} // namespace t16
+
+/// V = G L^-T on the bf16 pipe.  grid (8 * ceil(B / 8) * NP / 64), 256 threads; wave w of a workgroup owns 16 rows of G; in place: G -> V.
+/// Same workgroup -> (filter, row block) map as large_trsm_pipe (a filter's workgroups share one XCD).
+template <int NBMAX, int STAMP = 0>
+__global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<float> lv, t16::Planes pl, int nfilters, const int *skipped)
+{
+        using namespace t16;
+        static_assert(NBMAX == 17, "the chain lists 17 block columns");
+        __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][BLK];
+        const int NP = lv.NP, nblk = NP / LB;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nblk) * 8 + (blockIdx.x & 7), rb = slot % nblk;
+        if (b >= nfilters || skipped[b])
+                return;
+        const int n = d.n[b];
+        const int nb = large_blocks(n);
+        if (rb >= nb)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        float *grow = lv.G + (size_t)b * NP * NP + (size_t)(LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G (+ 4 lg)
+        const int a_h0 = li * PLD + 8 * (lg ^ (li & 7)), a_h1 = li * PLD + 8 * ((4 + lg) ^ (li & 7)); // this lane's operand rows, half 0 / 1 (swizzled chunk)
+        asm volatile("" ::: "a0", "a255"); // the strip
+        Seq seq(pl.Lq + (size_t)b * 3 * NP * NP, pl.Liq + (size_t)b * LARGE_NB_MAX * 3 * LB * LB, 0, nb, NP, tid);
+        Pipe pp;
+        pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3];
+        asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
+        // blocks 0, 1, 2 -> LDS
+        seq.issue(pp.b0);
+        seq.issue(pp.b1);
+        seq.issue(pp.b2);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        f4 g0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+                g0[t] = *reinterpret_cast<const f4 *>(grow + 16 * t);
+        if constexpr (STAMP)
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pp.tlast)::"memory");
+        Regs R;
+        load_planes(R.PA0, R.PA1, R.PA2, pp.b0, a_h0);
+        R.Pbh = R.Pbm = R.Pbl = (u4v){0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int k = 0; k < nb; ++k)
+        {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                        R.run[i] = R.e[i] = R.o[i] = 0.f;
+                chain<0, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
+                // ---- closing block: C = G - history (running sum + the sums of the last history block, which no later block has added),
+                // X = C Linv_k^T (Linv is lower triangular in tiles: output tile t needs c tiles <= t).  Set P holds the first-half rows of Linv_k.
+                asm volatile("s_nop 15" : "+v"(R.e), "+v"(R.o)); // MFMA results -> VALU
+                {
+                        const bool last_even = (k & 1) != 0; // history block k - 1
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                        {
+                                const f4 last = last_even ? tile4(R.e, t) : tile4(R.o, t);
+                                const f4 ct = k > 0 ? g0[t] - (tile4(R.run, t) + last) : g0[t];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        R.run[4 * t + r] = ct[r]; // C takes the place of the running sum
+                        }
+                        const float c01[8] = {R.run[0], R.run[1], R.run[2], R.run[3], R.run[4], R.run[5], R.run[6], R.run[7]};
+                        split8(c01, R.Pbh, R.Pbm, R.Pbl);
+                }
+                {
+                        typedef __attribute__((address_space(3))) unsigned short lds_us;
+                        const Dma dm = seq.next();
+                        const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u;
+                        const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1), a_nxt = (unsigned)(uintptr_t)(lds_us *)(pp.b1 + a_h0);
+                        // first half; behind it C tiles 2, 3 are split (-> set Q) and the second-half rows of Linv_k are read
+                        asm volatile(ASLAM_T16_C0 : "=&{v[32:47]}"(R.e), "+{v[64:79]}"(R.run), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 0, 0) : ASLAM_T16_SCRATCH);
+                        // second half (row tiles 2, 3); behind it the first operand of the next block column (history block 0: strip tiles 0, 1 -- for
+                        // k = 0 they are produced right here and read again below)
+                        asm volatile(ASLAM_T16_C1 : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, 0, 3) : ASLAM_T16_SCRATCH);
+                }
+                asm volatile("s_nop 15" : "+v"(R.e)); // MFMA results -> VALU / stores
+                f4 x[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        x[t] = tile4(R.e, t);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        *reinterpret_cast<f4 *>(grow + LB * k + 16 * t) = x[t];
+                switch (k)
+                {
+#define ASLAM_T16_KEEP(K)                                                                                              \
+        case K:                                                                                                        \
+                strip_write16<K>(x);                                                                                   \
+                break;
+                        ASLAM_T16_KEEP(0)
+                        ASLAM_T16_KEEP(1)
+                        ASLAM_T16_KEEP(2)
+                        ASLAM_T16_KEEP(3)
+                        ASLAM_T16_KEEP(4)
+                        ASLAM_T16_KEEP(5)
+                        ASLAM_T16_KEEP(6)
+                        ASLAM_T16_KEEP(7)
+                        ASLAM_T16_KEEP(8)
+                        ASLAM_T16_KEEP(9)
+                        ASLAM_T16_KEEP(10)
+                        ASLAM_T16_KEEP(11)
+                        ASLAM_T16_KEEP(12)
+                        ASLAM_T16_KEEP(13)
+                        ASLAM_T16_KEEP(14)
+                        ASLAM_T16_KEEP(15)
+                default:
+                        break; // the last block column is never a history block
+#undef ASLAM_T16_KEEP
+                }
+                if (k == 0)
+                {
+                        float s8[8];
+                        strip_read8<0>(s8);
+                        split8(s8, R.Pbh, R.Pbm, R.Pbl);
+                }
+                const int kn = min(k + 1, nb - 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        g0[t] = *reinterpret_cast<const f4 *>(grow + LB * kn + 16 * t);
+                pp.template end<16>();
+                pp.template stamp<STAMP>(4);
+        }
+        asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
+        if constexpr (STAMP)
+                if (tid == 0 && blockIdx.x == 0)
+                        for (int i = 0; i < 5; ++i)
+                                lv.Y[i] = (double)pp.ph[i];
+}
+
+/// L (lower block triangle of S after the factorisation) and Linv -> their bf16 planes (the form large_trsm_bf16 streams).  For the chains whose
+/// Cholesky kernels still write binary32 (the multi-workgroup chain of small batches; the fp32-MFMA resident Cholesky).  grid (NP / 64 + 1, B),
+/// 256 threads: workgroup x < NP / 64 splits block row x of L (blocks j < x), workgroup NP / 64 the inverses of the diagonal blocks.
+__global__ __launch_bounds__(256) void large_split_planes(DevView d, LargeView<float> lv, t16::Planes pl, const int *skipped)
+{
+        using namespace t16;
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        const int NP = lv.NP, nblk = NP / LB, nb = large_blocks(d.n[b]);
+        const int tid = threadIdx.x;
+        auto put = [&](const float *src, unsigned short *dst, size_t pstride) {
+                // src: 4 consecutive floats (columns c .. c+3 of a block, c = 4 (tid & 15)); dst: the permuted position of c in plane 0
+                const f4 v = *reinterpret_cast<const f4 *>(src);
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2(v[0], v[1], h0, m0, l0);
+                split2(v[2], v[3], h1, m1, l1);
+                *reinterpret_cast<u2v *>(dst) = (u2v){h0, h1};
+                *reinterpret_cast<u2v *>(dst + pstride) = (u2v){m0, m1};
+                *reinterpret_cast<u2v *>(dst + 2 * pstride) = (u2v){l0, l1};
+        };
+        const int c = 4 * (tid & 15), r0 = tid >> 4;
+        if ((int)blockIdx.x < nblk)
+        {
+                const int I = blockIdx.x;
+                if (I >= nb)
+                        return;
+                const float *S = lv.S + (size_t)b * NP * NP + (size_t)LB * I * NP;
+                unsigned short *Lq = pl.Lq + (size_t)b * 3 * NP * NP + (size_t)LB * I * NP;
+                for (int j = 0; j < I; ++j)
+                        for (int r = r0; r < LB; r += 16)
+                                put(S + (size_t)r * NP + LB * j + c, Lq + (size_t)r * NP + LB * j + perm_pos(c), (size_t)NP * NP);
+        }
+        else
+        {
+                const float *Li = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
+                unsigned short *Liq = pl.Liq + (size_t)b * LARGE_NB_MAX * 3 * LB * LB;
+                for (int k = 0; k < nb; ++k)
+                        for (int r = r0; r < LB; r += 16)
+                                put(Li + (size_t)k * LB * LB + r * LB + c, Liq + (size_t)k * 3 * LB * LB + r * LB + perm_pos(c), (size_t)LB * LB);
+        }
+}
+} // namespace aslam

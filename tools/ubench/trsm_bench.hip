@@ -168,6 +168,67 @@ int main(int argc, char **argv)
                 }
         }
         std::printf("large_trsm_pipe: max |V - host| / max |V| = %.2e (rows 0, 37, ... of filter %d)\n", worst / scale, B - 1);
+        // ---- the bf16-pipe sweep (ekf_large_trsm16.h): planes of L from large_split_planes, then the same check
+        t16::Planes pl = {};
+        {
+                CK(hipMalloc(&pl.Lq, sizeof(unsigned short) * 3 * M * B));
+                CK(hipMalloc(&pl.Liq, sizeof(unsigned short) * 3 * LARGE_NB_MAX * LB * LB * B));
+                CK(hipMemset(pl.Lq, 0, sizeof(unsigned short) * 3 * M * B));
+                const float msp = time_ms([&]() { hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pl, dskip); }, 3);
+                reset_G();
+                hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, B, dskip);
+                CK(hipDeviceSynchronize());
+                std::vector<float> V2(M);
+                CK(hipMemcpy(V2.data(), dG + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
+                double w2 = 0, s2 = 0, wr = 0;
+                int wi = -1, wc = -1;
+                for (int i = 0; i < NP; i += 37)
+                {
+                        std::vector<double> v(NP);
+                        for (int c = 0; c < NP; ++c)
+                        {
+                                double s = G[(size_t)i * NP + c];
+                                for (int q = 0; q < c; ++q)
+                                        s -= v[q] * (double)Lf[(size_t)c * NP + q];
+                                v[c] = s / (double)Lf[(size_t)c * NP + c];
+                        }
+                        for (int c = 0; c < NP; ++c)
+                        {
+                                const double e = std::fabs(v[c] - (double)V2[(size_t)i * NP + c]);
+                                if (e > w2)
+                                        w2 = e, wi = i, wc = c;
+                                s2 = std::fmax(s2, std::fabs(v[c]));
+                                wr = std::fmax(wr, std::fabs((double)V[(size_t)i * NP + c] - (double)V2[(size_t)i * NP + c]));
+                        }
+                }
+                std::printf("large_trsm_bf16: max |V - host| / max |V| = %.2e at (%d, %d); against large_trsm_pipe %.2e; large_split_planes %.3f ms for %d filters\n", w2 / s2, wi, wc,
+                            wr / s2, msp, B);
+                for (int bb : {15, 60, B})
+                {
+                        if (bb > B)
+                                break;
+                        const float m0 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, bb, dskip); }, 5);
+                        std::printf("  trsm_bf16 %3d filters: %7.3f ms\n", bb, m0);
+                }
+                {
+                        double *dY;
+                        CK(hipMalloc(&dY, sizeof(double) * 8));
+                        LargeView<float> lw = lv;
+                        lw.Y = dY;
+                        auto stamps = [&](const char *name, auto kern) {
+                                hipLaunchKernelGGL(kern, dim3(8 * ((15 + 7) / 8) * NB), dim3(256), 0, 0, d, lw, pl, 15, dskip);
+                                CK(hipDeviceSynchronize());
+                                double y[5];
+                                CK(hipMemcpy(y, dY, sizeof(y), hipMemcpyDeviceToHost));
+                                std::printf("  trsm_bf16 %-34s workgroup 0 of 255, shader cycles per block: first-half region %.0f, mid %.0f, second-half region %.0f, barrier %.0f; closing block %.0f; total %.0f\n",
+                                            name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, y[4] / 17, y[0] + y[1] + y[2] + y[3] + y[4]);
+                        };
+                        stamps("product", large_trsm_bf16<LARGE_NB_MAX, 1>);
+                        stamps("second half: no VALU", large_trsm_bf16<LARGE_NB_MAX, 2>);
+                        stamps("second half: no LDS reads", large_trsm_bf16<LARGE_NB_MAX, 3>);
+                        stamps("second half: MFMAs only", large_trsm_bf16<LARGE_NB_MAX, 4>);
+                }
+        }
         // ---- timings (the result does not matter: G is solved again in place).  DIAG bits: 1 = no global fetch of the L blocks (stale
         // LDS), 2 = no LDS stash and no barrier, 16 = no barrier (racy), 8 = in-kernel stamps
         const double mfma_per_wave = 64.0 * 136 + 40.0 * 17;
