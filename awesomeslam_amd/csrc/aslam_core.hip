@@ -559,7 +559,7 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
         A_(dev_alloc(c, &d.wait_cnt, B * cfg->max_wait, c->owned));
         A_(dev_alloc(c, &d.wait_n, B, c->owned));
 #ifdef ASLAM_STAMPS
-        A_(dev_alloc(c, &d.dbg, 64, c->owned));
+        A_(dev_alloc(c, &d.dbg, 64 + 1024, c->owned)); // [64 ..): diagnostic builds, last front-end launch, 100 MHz ticks per workgroup
 #endif
 #if ASLAM_HAVE_UKF
         if (rc == ASLAM_OK && cfg->filter == ASLAM_UKF)
@@ -1059,6 +1059,15 @@ int aslam_debug_fe_realtime(aslam_ctx *c, unsigned long long *out2)
         if (sync_ctx(c) != ASLAM_OK)
                 return ASLAM_ERR_HIP;
         HIP_TRY(hipMemcpy(out2, c->dv.dbg + 56, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return ASLAM_OK;
+}
+
+/* diagnostic builds only: 100 MHz ticks every workgroup (filter) spent inside the last large_frontend_kernel launch */
+int aslam_debug_fe_per_filter(aslam_ctx *c, unsigned long long *out, int count)
+{
+        if (sync_ctx(c) != ASLAM_OK)
+                return ASLAM_ERR_HIP;
+        HIP_TRY(hipMemcpy(out, c->dv.dbg + 64, (size_t)std::min(count, 1024) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return ASLAM_OK;
 }
 

@@ -44,6 +44,7 @@ template <typename T> struct LargeView
         double *Hc; // [B][NP/2][4] h00 h01 h10 h11 per landmark
         double *Y;  // [B][NP]
         T *Linv;    // [B][LARGE_NB_MAX][LB][LB]  inverses of the diagonal blocks of L
+        unsigned short *Lpl; // binary32 mode with the bf16-pipe TRSM: LPlanes::base (bf16 planes of L and of the inverses, written by large_chol_resident), else nullptr
 };
 
 // ---- MFMA traits -------------------------------------------------------------------------------------------------
@@ -82,6 +83,44 @@ template <> struct Mfma<float>
                 return (lane >> 4) * 4 + r;
         }
 };
+
+/// four floats -> their three bf16 planes, packed two to a register: x = h + m + l up to 2^-25 |x|.  Round to nearest at every level
+/// (v_cvt_pk_bf16_f32): with truncated pieces, which all carry the sign of x, the dropped terms of a split product have the sign of the product
+/// (large_syrk_bf16x3).
+typedef unsigned u2x __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16x3(const f4 &x, u2x &h, u2x &m, u2x &l)
+{
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+                const f2 v = {x[2 * e], x[2 * e + 1]};
+                const bf2 hh = __builtin_convertvector(v, bf2);
+                const f2 r1 = v - __builtin_convertvector(hh, f2);
+                const bf2 mm = __builtin_convertvector(r1, bf2);
+                const f2 r2 = r1 - __builtin_convertvector(mm, f2);
+                const bf2 ll = __builtin_convertvector(r2, bf2);
+                h[e] = __builtin_bit_cast(unsigned, hh), m[e] = __builtin_bit_cast(unsigned, mm), l[e] = __builtin_bit_cast(unsigned, ll);
+        }
+}
+
+/// Planes of L in HBM (binary32 mode; written by large_chol_resident, streamed by large_trsm_bf16 -- ekf_large_trsm16.h), one allocation, per
+/// filter: Lq [3][NP][NP] bf16 (row-major, columns permuted inside every 64-block; only blocks below the diagonal are read) followed by Liq
+/// [LARGE_NB_MAX][3][64][64] bf16 (the inverses of the diagonal blocks, columns permuted the same way): one buffer resource per filter serves both.
+struct LPlanes
+{
+        unsigned short *base;
+        __host__ __device__ static size_t lq_elems(int NP) { return (size_t)3 * NP * NP; }
+        __host__ __device__ static size_t per_filter(int NP) { return lq_elems(NP) + (size_t)(1088 / 64) * 3 * 64 * 64; }
+        __host__ __device__ unsigned short *Lq(int b, int NP) const { return base + (size_t)b * per_filter(NP); }
+        __host__ __device__ unsigned short *Liq(int b, int NP) const { return Lq(b, NP) + lq_elems(NP); }
+};
+/// position of column c (0 .. 63) of a block inside a permuted plane row: 32 h + 8 g + 4 w + r holds column 32 h + 16 w + 4 g + r
+__host__ __device__ __forceinline__ int lplane_pos(int c)
+{
+        return 32 * (c >> 5) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1) + (c & 3);
+}
 
 /// number of active 64-blocks: the n state rows plus the Y^T row
 __device__ __forceinline__ int large_blocks(int n)
@@ -265,6 +304,8 @@ __global__ __launch_bounds__(SMALL_WG) void large_frontend_kernel(DevView d, Lar
                 d.dbg[56] += __builtin_amdgcn_s_memrealtime() - stamp_rt0;
                 d.dbg[57] += 1;
         }
+        if (tid == 0 && blockIdx.x < 1024)
+                d.dbg[64 + blockIdx.x] = __builtin_amdgcn_s_memrealtime() - stamp_rt0; // every workgroup of the last launch (single stream group: the views are not shifted)
 #endif
 }
 

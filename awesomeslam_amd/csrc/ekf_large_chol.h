@@ -174,18 +174,38 @@ template <bool F32_DIAG> __device__ __forceinline__ bool factor_and_invert(doubl
 
 /// L (zeros above the diagonal) -> the 64x64 block at `Sdiag` (row stride NP), Linv = R^T -> `Linv_out` [64][64]: thread = row r, 16-column
 /// segment q.  T = float or double.
-template <typename T> __device__ __forceinline__ void store_block(const double *t, T *Sdiag, int NP, T *Linv_out, int tid)
+/// `Liq` (binary32 only, may be null): the inverse ALSO as three bf16 planes [3][64][64] with permuted columns (LPlanes, ekf_large.h): the thread's
+/// columns 16 q + 4 g .. + 3 go to positions 32 (q >> 1) + 8 g + 4 (q & 1) .. + 3.
+template <typename T> __device__ __forceinline__ void store_block(const double *t, T *Sdiag, int NP, T *Linv_out, int tid, unsigned short *Liq = nullptr)
 {
         const int r = tid >> 2, q = tid & 3, ti = r >> 4, a = r & 15;
         T *ls = Sdiag + (size_t)r * NP + 16 * q;
         T *io = Linv_out + r * LB + 16 * q;
         const double *Ltile = Lt(const_cast<double *>(t), ti, min(q, ti)) + a * TLD;
         const double *Rtile = Rt(const_cast<double *>(t), ti, min(q, ti)) + a;
+        T inv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e)
         {
                 ls[e] = (q <= ti) ? (T)Ltile[e] : (T)0;
-                io[e] = (q <= ti) ? (T)Rtile[e * TLD] : (T)0; // Linv(a, b) = R(b, a)
+                inv[e] = (q <= ti) ? (T)Rtile[e * TLD] : (T)0; // Linv(a, b) = R(b, a)
+                io[e] = inv[e];
+        }
+        if constexpr (sizeof(T) == 4)
+        {
+                if (Liq)
+                {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                        {
+                                u2x h, m, l;
+                                split_bf16x3((f4){(float)inv[4 * g], (float)inv[4 * g + 1], (float)inv[4 * g + 2], (float)inv[4 * g + 3]}, h, m, l);
+                                unsigned short *dst = Liq + r * LB + 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                                *reinterpret_cast<u2x *>(dst) = h;
+                                *reinterpret_cast<u2x *>(dst + LB * LB) = m;
+                                *reinterpret_cast<u2x *>(dst + 2 * LB * LB) = l;
+                        }
+                }
         }
 }
 } // namespace chol64
@@ -248,6 +268,12 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 sync_ctr = 0;
         unsigned nsig = 0, lost = 0;
         const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(Sb, 0, NP * NP * 4, 0x00020000);
+        // bf16 planes of L and of the inverses for large_trsm_bf16 (lv.Lpl != nullptr)
+        const LPlanes lpl = {lv.Lpl};
+        const unsigned qplane = lv.Lpl ? (unsigned)(NP * NP * 2) : 0u;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(lv.Lpl ? lpl.Lq(b, NP) : reinterpret_cast<unsigned short *>(Sb), 0, 3 * NP * NP * 2, 0x00020000);
+        const unsigned vq0 = (unsigned)(((16 * wave + li) * NP + 8 * lg) * 2); // this lane's row inside a block row, + 8 lg elements
+        unsigned short *Liq = lv.Lpl ? lpl.Liq(b, NP) : nullptr;
         bool ok = true;
         // STAMP (diagnostic build, tools/ubench/trsm_bench.hip): shader cycles of workgroup 0 by phase -> lv.Y[0 .. 3]: sweeps, conversion, diagonal
         // factorisation, stores + drain
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 const TrsmSeq seq_diag(Sb, Linv, I, I + 1, NP, tid); // the history blocks of the diagonal block: L(I, 0 .. I-1), this sweep's own output
                 TrsmPipe pp = {pipe, pipe + LB * TRSM_LDT, pipe + 2 * LB * TRSM_LDT, &sync_ctr, nsig, 0u};
                 f4 c[4];
-                trsm_sweep<0, true>(c, rsb, vs, I, seq, seq_diag, pp, a_off, tid);
+                trsm_sweep<0, true>(c, rsb, vs, I, seq, seq_diag, pp, a_off, tid, rq, vq0 + (unsigned)(LB * I * NP * 2), qplane);
                 nsig = pp.nsig;
                 lost |= pp.lost;
                 __syncthreads(); // every wave is done with the pipeline buffers: the tiles take their place
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 ASLAM_PH(1)
                 ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
                 ASLAM_PH(2)
-                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid);
+                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, Liq ? Liq + (size_t)I * 3 * LB * LB : nullptr);
                 // the next block row reads them back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();

@@ -399,9 +399,13 @@ __device__ __forceinline__ void trsm_pipe_start(f4 (&pf)[4], f4 (&a0)[4], f4 (&a
 /// blocks are L(nbk, j) = the X(:, j) this very sweep has just stored, so the pipeline is drained and restarted in front of them, and
 /// the sweep returns  c = S(nbk, nbk) - sum_j X(:, j) X(:, j)^T  (this wave's 16 rows: c[t][r] = column 16 t + 4 lg + r of row li)
 /// for the caller to factor.  `seq` walks Linv_0; L(1,0), Linv_1; ... (nb = nbk), `seq_diag` (CHOL only) starts at L(nbk, 0).
+/// `rq`, `vq`, `qplane` (CHOL only, qplane != 0): the solved blocks L(nbk, k) are ALSO written as three bf16 planes with permuted columns, the form
+/// large_trsm_bf16 streams (ekf_large_trsm16.h: position 32 (t >> 1) + 8 lg + 4 (t & 1) + r holds column 16 t + 4 lg + r, so row tiles 2 u and
+/// 2 u + 1 of a lane make one 16-byte store) -- buffer resource of the filter's planes, this lane's byte offset inside a plane (row, + 8 lg
+/// elements), bytes per plane.
 template <int DIAG, bool CHOL>
 __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], __amdgpu_buffer_rsrc_t rg, unsigned vg, int nbk, TrsmSeq &seq, const TrsmSeq &seq_diag, TrsmPipe &pp,
-                                           int a_off, int tid)
+                                           int a_off, int tid, __amdgpu_buffer_rsrc_t rq, unsigned vq, unsigned qplane)
 {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         auto gload = [&](int col) { // four floats of this lane's row at column `col` (wave-uniform) + 4 lg
@@ -478,6 +482,23 @@ __device__ __forceinline__ void trsm_sweep(f4 (&c)[4], __amdgpu_buffer_rsrc_t rg
                 for (int t = 0; t < 4; ++t)
                         __builtin_amdgcn_raw_buffer_store_b128((u4){__float_as_uint(x[t][0]), __float_as_uint(x[t][1]), __float_as_uint(x[t][2]), __float_as_uint(x[t][3])}, rg,
                                                                (int)vg, (LB * k + 16 * t) * 4, 0);
+                if constexpr (CHOL)
+                {
+                        if (qplane) // wave-uniform
+                        {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+                                {
+                                        u2x h0, m0, l0, h1, m1, l1;
+                                        split_bf16x3(x[2 * u], h0, m0, l0);
+                                        split_bf16x3(x[2 * u + 1], h1, m1, l1);
+                                        const int so = (LB * k + 32 * u) * 2;
+                                        __builtin_amdgcn_raw_buffer_store_b128((u4){h0[0], h0[1], h1[0], h1[1]}, rq, (int)vq, so, 0);
+                                        __builtin_amdgcn_raw_buffer_store_b128((u4){m0[0], m0[1], m1[0], m1[1]}, rq, (int)vq, so + (int)qplane, 0);
+                                        __builtin_amdgcn_raw_buffer_store_b128((u4){l0[0], l0[1], l1[0], l1[1]}, rq, (int)vq, so + 2 * (int)qplane, 0);
+                                }
+                        }
+                }
                 switch (k)
                 {
 #define ASLAM_TRSM_KEEP(K)                                                                                             \
@@ -553,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_pipe(DevView d, LargeView<f
                 sync_ctr = 0; // (the first barrier of the sweep publishes it)
         TrsmPipe pp = {lds[0], lds[1], lds[2], &sync_ctr, 0u, 0u};
         f4 c[4];
-        trsm_sweep<DIAG, false>(c, rg, vg, nb, seq, seq, pp, a_off, tid);
+        trsm_sweep<DIAG, false>(c, rg, vg, nb, seq, seq, pp, a_off, tid, rg, 0u, 0u);
         if (pp.lost && lane == 0)
                 atomicOr(&d.status[b], 16u); // ASLAM_ST_INTERNAL
         if constexpr (DIAG & 8)

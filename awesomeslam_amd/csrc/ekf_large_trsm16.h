@@ -39,19 +39,11 @@ constexpr int PLANE = LB * PLD;   // elements of one plane of a staged block
 constexpr int BLK = 3 * PLANE;    // a staged block: three planes, 24 576 bytes
 constexpr int NBUF = 4;           // LDS buffers: block i multiplied, i + 1 complete, i + 2 / i + 3 in flight
 
-/// position of column c (0 .. 63) of a block inside a permuted plane row
+typedef LPlanes Planes; // (ekf_large.h)
 __host__ __device__ __forceinline__ int perm_pos(int c)
 {
-        return 32 * (c >> 5) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1) + (c & 3);
+        return lplane_pos(c);
 }
-
-/// Planes of one filter's L in HBM.  Lq: [3][NP][NP] bf16, row-major, columns permuted inside every 64-block (only blocks below the diagonal
-/// are read); Liq: [LARGE_NB_MAX][3][64][64] bf16, the inverses of the diagonal blocks, columns permuted the same way.
-struct Planes
-{
-        unsigned short *Lq;
-        unsigned short *Liq;
-};
 
 /// two floats -> the three bf16 pieces of each, packed (lo = first): round to nearest even at every level
 __device__ __forceinline__ void split2(float a, float b, unsigned &h, unsigned &m, unsigned &l)
@@ -168,6 +160,14 @@ template <int NM> __device__ __forceinline__ void interleave()
         }
 }
 
+/// a wave-uniform pointer the compiler computed with vector instructions (64-bit multiplies) -> scalar registers
+template <typename T> __device__ __forceinline__ T *uniform_ptr(T *p)
+{
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 /// One block's LDS-DMA descriptor: the regions issue its six one-KiB pieces per wave (piece i: plane i >> 1, rows 8 (4 (i & 1) + wave) .. + 7 of the
 /// block; lane l = row l >> 3 of the piece, the 16 bytes that belong at chunk position l & 7 of that row: logical chunk (l & 7) ^ (l >> 3))
 struct Dma
@@ -181,12 +181,12 @@ struct Dma
 struct Seq
 {
         int k, j, nb, NP, wave;
-        __amdgpu_buffer_rsrc_t rl, ri;
+        __amdgpu_buffer_rsrc_t rs; // the filter's planes: L, then the inverses (Planes)
+        unsigned inv0;             // byte offset of the inverses
         unsigned vo_l, vo_i;
-        __device__ __forceinline__ Seq(const unsigned short *Lq, const unsigned short *Liq, int k0, int nb_, int NP_, int tid)
+        __device__ __forceinline__ Seq(const Planes &pl, int b, int k0, int nb_, int NP_, int tid)
             : k(k0), j(0), nb(nb_), NP(NP_), wave(__builtin_amdgcn_readfirstlane(tid >> 6)),
-              rl(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Lq), 0, 3 * NP_ * NP_ * 2, 0x00020000)),
-              ri(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Liq), 0, LARGE_NB_MAX * 3 * LB * LB * 2, 0x00020000))
+              rs(__builtin_amdgcn_make_buffer_rsrc(uniform_ptr(pl.Lq(b, NP_)), 0, (int)(Planes::per_filter(NP_) * 2), 0x00020000)), inv0((unsigned)(Planes::lq_elems(NP_) * 2))
         {
                 const int l = tid & 63, r = l >> 3, lc = (l & 7) ^ r;
                 vo_l = (unsigned)((r * NP_ + 8 * lc) * 2);
@@ -197,13 +197,13 @@ struct Seq
         {
                 const bool hist = j < k;
                 Dma dm;
-                dm.rsrc = hist ? rl : ri;
+                dm.rsrc = rs;
                 dm.voff = hist ? vo_l : vo_i;
-                const unsigned base = hist ? (unsigned)(((LB * k) * NP + LB * j) * 2) : (unsigned)(k * 3 * LB * LB * 2);
+                const unsigned base = hist ? (unsigned)(((LB * k) * NP + LB * j) * 2) : inv0 + (unsigned)(k * 3 * LB * LB * 2);
+                // piece i: plane i >> 1, rows 8 (4 (i & 1) + wave) ..  (no arrays in this struct: hipcc moves a struct with selected-between arrays to LDS)
                 const unsigned ps = hist ? (unsigned)(NP * NP * 2) : (unsigned)(LB * LB * 2), r8 = hist ? (unsigned)(8 * NP * 2) : (unsigned)(8 * LB * 2);
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-                        dm.so[i] = base + (unsigned)(i >> 1) * ps + (unsigned)(4 * (i & 1) + wave) * r8;
+                const unsigned w0 = base + (unsigned)wave * r8, w1 = w0 + 4u * r8;
+                dm.so[0] = w0, dm.so[1] = w1, dm.so[2] = w0 + ps, dm.so[3] = w1 + ps, dm.so[4] = w0 + 2u * ps, dm.so[5] = w1 + 2u * ps;
                 const bool adv = !hist && k + 1 < nb;
                 j = hist ? j + 1 : (adv ? 0 : j);
                 k += adv ? 1 : 0;
@@ -214,7 +214,7 @@ struct Seq
         {
                 typedef __attribute__((address_space(3))) unsigned short lds_us;
                 const Dma dm = next();
-                const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)dst + (unsigned)wave * 1024u;
+                const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)dst + (unsigned)wave * 1024u));
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                         asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
@@ -233,7 +233,7 @@ struct Pipe
 {
         unsigned short *b0, *b1, *b2, *b3;
         // diagnostic builds (STAMP): shader cycles by phase -- 0 first-half region, 1 between the halves, 2 second-half region, 3 end (barrier), 4 closing block
-        unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+        unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0; // 5 .. 8: inside the closing block (C + split, first half, second half, stores + strip)
         template <int STAMP> __device__ __forceinline__ void stamp(int i)
         {
                 if constexpr (STAMP)
@@ -294,7 +294,7 @@ template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &
 {
         typedef __attribute__((address_space(3))) unsigned short lds_us;
         const Dma dm = seq.next();
-        const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u;
+        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u));
         const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1); // the second half of this block
         if constexpr (J == 0)
                 asm volatile(ASLAM_T16_H0_E : "=&{v[32:47]}"(R.e), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 16 * J + 8, 0) : ASLAM_T16_SCRATCH);
@@ -385,10 +385,29 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
         if (rb >= nb)
                 return;
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *grow = lv.G + (size_t)b * NP * NP + (size_t)(LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G (+ 4 lg)
+        float *grow = lv.G + (size_t)b * NP * NP + (size_t)(LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G (+ 4 lg): the stores of V
+        // The slices of G arrive by LDS-DMA like the blocks of L (four one-KiB pieces per wave and block column: its 16 rows x 64 columns, piece i =
+        // rows 4 i .. 4 i + 3, lane l = row l >> 4, 16-byte chunk l & 15), so that every load of the loop is counted by the same s_waitcnt vmcnt
+        // arithmetic: a load the compiler issues makes hipcc wait on ITS count of outstanding loads, which knows nothing of the DMA pieces in
+        // flight and drains them.
+        __shared__ __attribute__((aligned(1024))) float gl[4][16 * LB];
+        typedef __attribute__((address_space(3))) float lds_f;
+        const __amdgpu_buffer_rsrc_t rgd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(lv.G + (size_t)b * NP * NP), 0, NP * NP * 4, 0x00020000);
+        const unsigned g_vo = (unsigned)(((lane >> 4) * NP + 4 * (lane & 15)) * 4);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned g_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_f *)gl[wv]);
+        const unsigned g_so0 = (unsigned)((LB * rb + 16 * wv) * NP * 4), g_rs4 = (unsigned)(4 * NP * 4);
+        auto g_issue = [&](int kcol) { // this wave's 16 x 64 slice of block column kcol -> gl[wave]
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                                     :
+                                     : "s"(g_lds), "n"(i * 1024), "v"(g_vo), "s"(rgd), "s"(g_so0 + (unsigned)i * g_rs4 + (unsigned)(LB * kcol * 4))
+                                     : "m0", "scc", "memory");
+        };
         const int a_h0 = li * PLD + 8 * (lg ^ (li & 7)), a_h1 = li * PLD + 8 * ((4 + lg) ^ (li & 7)); // this lane's operand rows, half 0 / 1 (swizzled chunk)
         asm volatile("" ::: "a0", "a255"); // the strip
-        Seq seq(pl.Lq + (size_t)b * 3 * NP * NP, pl.Liq + (size_t)b * LARGE_NB_MAX * 3 * LB * LB, 0, nb, NP, tid);
+        Seq seq(pl, b, 0, nb, NP, tid);
         Pipe pp;
         pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3];
         asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
@@ -396,11 +415,8 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
         seq.issue(pp.b0);
         seq.issue(pp.b1);
         seq.issue(pp.b2);
+        g_issue(0);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        f4 g0[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-                g0[t] = *reinterpret_cast<const f4 *>(grow + 16 * t);
         if constexpr (STAMP)
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pp.tlast)::"memory");
         Regs R;
@@ -415,6 +431,14 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                 chain<0, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
                 // ---- closing block: C = G - history (running sum + the sums of the last history block, which no later block has added),
                 // X = C Linv_k^T (Linv is lower triangular in tiles: output tile t needs c tiles <= t).  Set P holds the first-half rows of Linv_k.
+                // this block column's slice of G: issued one block column ago; at most the six pieces of the last history block are younger
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                f4 g0[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                        g0[t] = *reinterpret_cast<const f4 *>(&gl[wv][li * LB + 16 * t + 4 * lg]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                g_issue(min(k + 1, nb - 1)); // the next slice (ahead of this block's pieces of L: Pipe::end counts on that order)
                 asm volatile("s_nop 15" : "+v"(R.e), "+v"(R.o)); // MFMA results -> VALU
                 {
                         const bool last_even = (k & 1) != 0; // history block k - 1
@@ -430,17 +454,20 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                         const float c01[8] = {R.run[0], R.run[1], R.run[2], R.run[3], R.run[4], R.run[5], R.run[6], R.run[7]};
                         split8(c01, R.Pbh, R.Pbm, R.Pbl);
                 }
+                pp.template stamp<STAMP>(5);
                 {
                         typedef __attribute__((address_space(3))) unsigned short lds_us;
                         const Dma dm = seq.next();
-                        const unsigned ldsw = (unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u;
+                        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u));
                         const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1), a_nxt = (unsigned)(uintptr_t)(lds_us *)(pp.b1 + a_h0);
                         // first half; behind it C tiles 2, 3 are split (-> set Q) and the second-half rows of Linv_k are read
                         asm volatile(ASLAM_T16_C0 : "=&{v[32:47]}"(R.e), "+{v[64:79]}"(R.run), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 0, 0) : ASLAM_T16_SCRATCH);
+                        pp.template stamp<STAMP>(6);
                         // second half (row tiles 2, 3); behind it the first operand of the next block column (history block 0: strip tiles 0, 1 -- for
                         // k = 0 they are produced right here and read again below)
                         asm volatile(ASLAM_T16_C1 : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, 0, 3) : ASLAM_T16_SCRATCH);
                 }
+                pp.template stamp<STAMP>(7);
                 asm volatile("s_nop 15" : "+v"(R.e)); // MFMA results -> VALU / stores
                 f4 x[4];
 #pragma unroll
@@ -481,17 +508,14 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                         strip_read8<0>(s8);
                         split8(s8, R.Pbh, R.Pbm, R.Pbl);
                 }
-                const int kn = min(k + 1, nb - 1);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                        g0[t] = *reinterpret_cast<const f4 *>(grow + LB * kn + 16 * t);
+                pp.template stamp<STAMP>(8);
                 pp.template end<16>();
                 pp.template stamp<STAMP>(4);
         }
         asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
         if constexpr (STAMP)
                 if (tid == 0 && blockIdx.x == 0)
-                        for (int i = 0; i < 5; ++i)
+                        for (int i = 0; i < 9; ++i)
                                 lv.Y[i] = (double)pp.ph[i];
 }
 
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(256) void large_split_planes(DevView d, LargeView<f
                 if (I >= nb)
                         return;
                 const float *S = lv.S + (size_t)b * NP * NP + (size_t)LB * I * NP;
-                unsigned short *Lq = pl.Lq + (size_t)b * 3 * NP * NP + (size_t)LB * I * NP;
+                unsigned short *Lq = pl.Lq(b, NP) + (size_t)LB * I * NP;
                 for (int j = 0; j < I; ++j)
                         for (int r = r0; r < LB; r += 16)
                                 put(S + (size_t)r * NP + LB * j + c, Lq + (size_t)r * NP + LB * j + perm_pos(c), (size_t)NP * NP);
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(256) void large_split_planes(DevView d, LargeView<f
         else
         {
                 const float *Li = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
-                unsigned short *Liq = pl.Liq + (size_t)b * LARGE_NB_MAX * 3 * LB * LB;
+                unsigned short *Liq = pl.Liq(b, NP);
                 for (int k = 0; k < nb; ++k)
                         for (int r = r0; r < LB; r += 16)
                                 put(Li + (size_t)k * LB * LB + r * LB + c, Liq + (size_t)k * 3 * LB * LB + r * LB + perm_pos(c), (size_t)LB * LB);

@@ -114,7 +114,7 @@ struct StepArgs
 /// scalars of one filter, kept in LDS while the kernel runs
 struct SmallShared
 {
-        int n, flags, sn, wn, nnew, grew, grow_from, any_miss, obs_new, nobs, skip;
+        int n, flags, sn, wn, nnew, grew, grow_from, any_miss, any_promote, obs_new, nobs, skip;
         uint32_t status;
         float vx, az, dt, yaw;
         double px, py, tvx, twz, a00, a10;
@@ -1140,84 +1140,149 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 }
         }
         __syncthreads();
-        if (tid == 0 && sm.any_miss)
+        if (sm.any_miss)
         {
-                // unassociated observations go through the wait-list in message order (they touch nothing the associated
-                // ones touch); counts only change here, so without a miss there is nothing to promote either
-                int wn = sm.wn;
+                // Unassociated observations go through the wait-list in message order (they touch nothing the associated ones touch); counts only
+                // change here, so without a miss there is nothing to promote either.  The observations are sequential -- a push changes the list
+                // the next one searches -- but the nearest-neighbour scan of ONE observation (updateNewLandmarkWait, ekf.cpp:217-253: strict
+                // `dist < mindist` over the entries in order, starting from entry 0) is spread over the workgroup: every thread scans its entries
+                // in ascending order with the same strict compare, the partial results are combined by (distance, index), and entry 0 stays the
+                // starting value (kept on ties and when its distance is a NaN), so the winner is the sequential scan's bit for bit.  One thread
+                // did all of it before round 3: with a 2048-entry list a single miss cost ~30 k cycles, and the slowest filter of a launch set
+                // the front end's 330 - 420 us (profiles/r03_experiments.md).
                 const int wcap = min(d.max_wait, WAIT_CAP);
-                for (int j = 0; j < sm.sn; ++j)
+                const int lane = tid & 63, wv = tid >> 6;
+                constexpr int NWAVE = SMALL_WG / 64;
+                for (int j = 0; j < sm.sn; ++j) // (workgroup-uniform: every condition below reads LDS values published by a barrier)
                 {
                         if (n0 != 3 && sMd[j] < MIN_DIST_THRESH)
                                 continue;
-                        // updateNewLandmarkWait, ekf.cpp:217-253
-                        bool push = (wn == 0);
-                        if (!push)
+                        const int wn = sm.wn;
+                        if (wn > 0)
                         {
-                                int corr = 0;
-                                float mind = eulerDistance(sPx[j], sPy[j], sWx[0], sWy[0]);
-                                for (int i = 1; i < wn; ++i)
+                                const float px = sPx[j], py = sPy[j];
+                                float bd = __builtin_inff();
+                                int bi = 0x7fffffff;
+                                for (int i = 1 + tid; i < wn; i += SMALL_WG)
                                 {
-                                        const float dd = eulerDistance(sPx[j], sPy[j], sWx[i], sWy[i]);
-                                        if (dd < mind)
+                                        const float dd = eulerDistance(px, py, sWx[i], sWy[i]);
+                                        if (dd < bd)
                                         {
-                                                corr = i;
-                                                mind = dd;
+                                                bd = dd;
+                                                bi = i;
                                         }
                                 }
-                                if (mind < MIN_DIST_THRESH)
-                                        sWc[corr]++;
-                                else
-                                        push = true;
-                        }
-                        if (push)
-                        {
-                                if (wn < wcap)
+#pragma unroll
+                                for (int off = 32; off >= 1; off >>= 1)
                                 {
-                                        sWr[wn] = sSr[j];
-                                        sWb[wn] = sSb[j];
-                                        sWx[wn] = sPx[j];
-                                        sWy[wn] = sPy[j];
-                                        sWc[wn] = 1;
-                                        ++wn;
+                                        const float od = __shfl_xor(bd, off);
+                                        const int oi = __shfl_xor(bi, off);
+                                        if (od < bd || (od == bd && oi < bi))
+                                        {
+                                                bd = od;
+                                                bi = oi;
+                                        }
                                 }
-                                else
-                                        sm.status |= 2u; // ASLAM_ST_WAIT_OVERFLOW
-                        }
-                }
-                sm.wn = wn;
-                // promotion, ekf.cpp:187-195
-                int nnew = 0;
-                for (int i = 0; i < wn; ++i)
-                {
-                        if (sWc[i] == MIN_LANDMARK_OCC)
-                        {
-                                if (nnew < NEW_CAP)
-                                        sNew[nnew] = i;
-                                ++nnew;
-                                sWc[i] += 1;
-                        }
-                }
-                if (nnew)
-                {
-                        // updateNewLandmark, ekf.cpp:255-290
-                        const int nn = n0 + 2 * nnew;
-                        if (nn >= d.dim_cap)
-                                sm.status |= 1u; // ASLAM_ST_GROWTH_REFUSED
-                        else
-                        {
-                                for (int k = 0; k < nnew; ++k)
+                                if (lane == 0)
                                 {
-                                        const int e = sNew[k];
-                                        const double zr = (double)sWr[e], zb = (double)sWb[e];
-                                        sZ[n0 + 2 * k] = zr;
-                                        sZ[n0 + 2 * k + 1] = zb;
-                                        sX[n0 + 2 * k] = sZ[0] + zr * cos(sZ[2] + zb);
-                                        sX[n0 + 2 * k + 1] = sZ[1] + zr * sin(sZ[2] + zb);
+                                        L.sPd[wv] = bd; // (the association scratch is free here)
+                                        L.sPi[wv] = bi;
                                 }
-                                sm.grow_from = n0;
-                                sm.n = nn;
-                                sm.grew = 1;
+                        }
+                        __syncthreads();
+                        if (tid == 0)
+                        {
+                                bool push = (wn == 0);
+                                if (!push)
+                                {
+                                        int corr = 0;
+                                        float mind = eulerDistance(sPx[j], sPy[j], sWx[0], sWy[0]);
+                                        float bd = L.sPd[0];
+                                        int bi = L.sPi[0];
+                                        for (int w = 1; w < NWAVE; ++w)
+                                        {
+                                                const float od = L.sPd[w];
+                                                const int oi = L.sPi[w];
+                                                if (od < bd || (od == bd && oi < bi))
+                                                {
+                                                        bd = od;
+                                                        bi = oi;
+                                                }
+                                        }
+                                        if (bd < mind)
+                                        {
+                                                corr = bi;
+                                                mind = bd;
+                                        }
+                                        if (mind < MIN_DIST_THRESH)
+                                                sWc[corr]++;
+                                        else
+                                                push = true;
+                                }
+                                if (push)
+                                {
+                                        if (wn < wcap)
+                                        {
+                                                sWr[wn] = sSr[j];
+                                                sWb[wn] = sSb[j];
+                                                sWx[wn] = sPx[j];
+                                                sWy[wn] = sPy[j];
+                                                sWc[wn] = 1;
+                                                sm.wn = wn + 1;
+                                        }
+                                        else
+                                                sm.status |= 2u; // ASLAM_ST_WAIT_OVERFLOW
+                                }
+                        }
+                        __syncthreads();
+                }
+                // promotion, ekf.cpp:187-195: rare -- every thread looks at its entries, one walks the list in order only if there is one
+                if (tid == 0)
+                        sm.any_promote = 0;
+                __syncthreads();
+                {
+                        bool mine = false;
+                        for (int i = tid; i < sm.wn; i += SMALL_WG)
+                                mine = mine || (sWc[i] == MIN_LANDMARK_OCC);
+                        if (mine)
+                                sm.any_promote = 1;
+                }
+                __syncthreads();
+                if (tid == 0 && sm.any_promote)
+                {
+                        const int wn = sm.wn;
+                        int nnew = 0;
+                        for (int i = 0; i < wn; ++i)
+                        {
+                                if (sWc[i] == MIN_LANDMARK_OCC)
+                                {
+                                        if (nnew < NEW_CAP)
+                                                sNew[nnew] = i;
+                                        ++nnew;
+                                        sWc[i] += 1;
+                                }
+                        }
+                        if (nnew)
+                        {
+                                // updateNewLandmark, ekf.cpp:255-290
+                                const int nn = n0 + 2 * nnew;
+                                if (nn >= d.dim_cap)
+                                        sm.status |= 1u; // ASLAM_ST_GROWTH_REFUSED
+                                else
+                                {
+                                        for (int k = 0; k < nnew; ++k)
+                                        {
+                                                const int e = sNew[k];
+                                                const double zr = (double)sWr[e], zb = (double)sWb[e];
+                                                sZ[n0 + 2 * k] = zr;
+                                                sZ[n0 + 2 * k + 1] = zb;
+                                                sX[n0 + 2 * k] = sZ[0] + zr * cos(sZ[2] + zb);
+                                                sX[n0 + 2 * k + 1] = sZ[1] + zr * sin(sZ[2] + zb);
+                                        }
+                                        sm.grow_from = n0;
+                                        sm.n = nn;
+                                        sm.grew = 1;
+                                }
                         }
                 }
         }

@@ -23,3 +23,9 @@ print('large frontend cycles/callback (workgroup 0): total %.0f'%cyc.sum())
 for nm,c in zip(NAMES,cyc): print(f'   {nm:16s} {c:9.0f}')
 for nm,c in zip(['intake+copy','toPoint+narrow','scan','combine+Z','wait walk','A'],cyc[5:11]): print(f'      fe: {nm:16s} {c:9.0f}')
 
+
+if hasattr(lib,'aslam_debug_fe_per_filter'):
+    pf=(ctypes.c_ulonglong*1024)(); lib.aslam_debug_fe_per_filter(core._h,pf,B)
+    us=np.array(list(pf)[:B],dtype=np.float64)/100.0
+    print('front end, last launch, us inside the kernel per workgroup (filter): min %.0f  median %.0f  mean %.0f  p90 %.0f  max %.0f'%(us.min(),np.median(us),us.mean(),np.percentile(us,90),us.max()))
+    st=np.array([core.state(b,with_P=False)[0].shape[0] for b in range(min(B,8))]); print('   dims of the first filters',st, ' wait-list sizes', [len(core.wait_list(b,4096)[0]) for b in range(min(B,8))])

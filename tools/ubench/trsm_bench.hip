@@ -171,9 +171,8 @@ int main(int argc, char **argv)
         // ---- the bf16-pipe sweep (ekf_large_trsm16.h): planes of L from large_split_planes, then the same check
         t16::Planes pl = {};
         {
-                CK(hipMalloc(&pl.Lq, sizeof(unsigned short) * 3 * M * B));
-                CK(hipMalloc(&pl.Liq, sizeof(unsigned short) * 3 * LARGE_NB_MAX * LB * LB * B));
-                CK(hipMemset(pl.Lq, 0, sizeof(unsigned short) * 3 * M * B));
+                CK(hipMalloc(&pl.base, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
+                CK(hipMemset(pl.base, 0, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
                 const float msp = time_ms([&]() { hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pl, dskip); }, 3);
                 reset_G();
                 hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, B, dskip);
@@ -212,16 +211,17 @@ int main(int argc, char **argv)
                 }
                 {
                         double *dY;
-                        CK(hipMalloc(&dY, sizeof(double) * 8));
+                        CK(hipMalloc(&dY, sizeof(double) * 16));
                         LargeView<float> lw = lv;
                         lw.Y = dY;
                         auto stamps = [&](const char *name, auto kern) {
                                 hipLaunchKernelGGL(kern, dim3(8 * ((15 + 7) / 8) * NB), dim3(256), 0, 0, d, lw, pl, 15, dskip);
                                 CK(hipDeviceSynchronize());
-                                double y[5];
+                                double y[9];
                                 CK(hipMemcpy(y, dY, sizeof(y), hipMemcpyDeviceToHost));
                                 std::printf("  trsm_bf16 %-34s workgroup 0 of 255, shader cycles per block: first-half region %.0f, mid %.0f, second-half region %.0f, barrier %.0f; closing block %.0f; total %.0f\n",
-                                            name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, y[4] / 17, y[0] + y[1] + y[2] + y[3] + y[4]);
+                                            name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, (y[4] + y[5] + y[6] + y[7] + y[8]) / 17, y[0] + y[1] + y[2] + y[3] + y[4] + y[5] + y[6] + y[7] + y[8]);
+                                std::printf("      closing block: C + split %.0f, first half %.0f, second half %.0f, stores + strip %.0f, wait + barrier %.0f\n", y[5] / 17, y[6] / 17, y[7] / 17, y[8] / 17, y[4] / 17);
                         };
                         stamps("product", large_trsm_bf16<LARGE_NB_MAX, 1>);
                         stamps("second half: no VALU", large_trsm_bf16<LARGE_NB_MAX, 2>);
@@ -293,6 +293,36 @@ int main(int argc, char **argv)
                         CK(hipMemsetAsync(dLinv, 0xff, sizeof(float) * NB * LB * LB * B, 0)); // NaNs: nothing may be read before it is written
                 };
                 reset_S();
+                {
+                        // the bf16 planes large_chol_resident writes beside L must be, bit for bit, what large_split_planes makes of that L
+                        LargeView<float> lp = lv;
+                        LPlanes pa = {}, pb = {};
+                        const size_t pe = LPlanes::per_filter(NP) * B;
+                        CK(hipMalloc(&pa.base, sizeof(unsigned short) * pe));
+                        CK(hipMalloc(&pb.base, sizeof(unsigned short) * pe));
+                        CK(hipMemset(pa.base, 0, sizeof(unsigned short) * pe));
+                        CK(hipMemset(pb.base, 0, sizeof(unsigned short) * pe));
+                        lp.Lpl = pa.base;
+                        hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lp, dskip);
+                        hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
+                        CK(hipDeviceSynchronize());
+                        std::vector<unsigned short> ha(LPlanes::per_filter(NP)), hb(LPlanes::per_filter(NP));
+                        CK(hipMemcpy(ha.data(), pa.Lq(B - 1, NP), sizeof(unsigned short) * ha.size(), hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(hb.data(), pb.Lq(B - 1, NP), sizeof(unsigned short) * hb.size(), hipMemcpyDeviceToHost));
+                        size_t diff = 0, first = 0;
+                        for (size_t i = 0; i < ha.size(); ++i)
+                                if (ha[i] != hb[i] && !diff++)
+                                        first = i;
+                        std::printf("large_chol_resident's bf16 planes against large_split_planes of its L: %zu of %zu elements differ%s\n", diff, ha.size(),
+                                    diff ? "" : " (bit-identical)");
+                        if (diff)
+                                std::printf("   first difference at element %zu (plane %zu, row %zu, position %zu)\n", first, first / M, (first % M) / NP, first % NP);
+                        const float mc = time_ms([&]() { hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lp, dskip); }, 3);
+                        std::printf("  chol_resident writing the planes too, %d filters: %7.3f ms (the factor of a factor: timing only)\n", B, mc);
+                        CK(hipFree(pa.base));
+                        CK(hipFree(pb.base));
+                        reset_S();
+                }
                 hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lv, dskip);
                 CK(hipDeviceSynchronize());
                 std::vector<float> Lg(M), Lig((size_t)NB * LB * LB);
