@@ -25,6 +25,8 @@
 // (f64 or f32 inputs), operands staged through LDS.
 #pragma once
 
+#include <type_traits>
+
 #include "small_common.h"
 
 namespace aslam
@@ -1150,6 +1152,29 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
         }
 }
 
+/// Sum of x over the 64 lanes of a wave, valid in lane 63, by DPP moves only (quad permutes, row mirrors, row broadcasts: VALU instructions).
+/// __shfl_xor is a ds_bpermute -- an LDS crossbar instruction: the five binary64 sums per row of large_x_update<.., SLIM> were 60 of them per
+/// wave and made the kernel LDS-bound (393 us per 256 filters against 217 for the one sum of round 2; profiles/r03_experiments.md).
+__device__ __forceinline__ double wave_sum_dpp(double x)
+{
+        auto step = [](double v, auto ctrl, auto rmask) {
+                constexpr int C = decltype(ctrl)::value, RM = decltype(rmask)::value;
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+                const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, RM, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, RM, 0xf, false);
+                const double o = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+                return v + o; // lanes outside the row mask add the 0 of `old`
+        };
+        using std::integral_constant;
+        x = step(x, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});  // quad_perm [1,0,3,2]
+        x = step(x, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});  // quad_perm [2,3,0,1]
+        x = step(x, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}); // row_half_mirror
+        x = step(x, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}); // row_mirror: every lane holds its row's sum
+        x = step(x, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}); // row_bcast:15 into rows 1, 3
+        x = step(x, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2, 3: lane 63 holds the wave's sum
+        return x;
+}
+
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay
 /// mode also writes the pose of this callback.
 ///
@@ -1195,15 +1220,8 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
                                 d2 = fma(ve, (double)u2[e], d2);
                         }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1)
-                {
-                        dd += __shfl_xor(dd, off);
-                        d0 += __shfl_xor(d0, off);
-                        d1 += __shfl_xor(d1, off);
-                        d2 += __shfl_xor(d2, off);
-                }
-                if (lane == 0)
+                dd = wave_sum_dpp(dd), d0 = wave_sum_dpp(d0), d1 = wave_sum_dpp(d1), d2 = wave_sum_dpp(d2);
+                if (lane == 63)
                 {
                         double *P = lv.P + (size_t)b * NP * NP;
                         double *prow = P + (size_t)a * NP;
@@ -1228,10 +1246,8 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
                                 acc = fma((double)v[e], (double)w[e], acc);
                 }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-                acc += __shfl_xor(acc, off);
-        if (lane == 0)
+        acc = wave_sum_dpp(acc);
+        if (lane == 63)
         {
                 const double xa = d.X[(size_t)b * NP + a] + acc;
                 d.X[(size_t)b * NP + a] = xa;

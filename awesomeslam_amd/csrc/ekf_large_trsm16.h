@@ -181,6 +181,8 @@ struct Dma
 struct Seq
 {
         int k, j, nb, NP, wave;
+        int diag = 0; // Cholesky, diagonal block column: only the history blocks L(k, 0 .. k-1) exist -- the inverse of block k is written AFTER this
+                      // sweep, and a prefetch of it now would leave a stale copy in the CU's L1 for the next block row to hit
         __amdgpu_buffer_rsrc_t rs; // the filter's planes: L, then the inverses (Planes)
         unsigned inv0;             // byte offset of the inverses
         unsigned vo_l, vo_i;
@@ -195,6 +197,8 @@ struct Seq
         /// the next block of the sequence
         __device__ __forceinline__ Dma next()
         {
+                if (diag && j >= k)
+                        j = max(k - 1, 0); // (past the end of the diagonal column's history: the last block again)
                 const bool hist = j < k;
                 Dma dm;
                 dm.rsrc = rs;
@@ -367,78 +371,103 @@ __device__ __forceinline__ void split_c(const f4 (&c)[4], int h, u4v &bh, u4v &b
 }
 } // namespace t16
 
-/// V = G L^-T on the bf16 pipe.  grid (8 * ceil(B / 8) * NP / 64), 256 threads; wave w of a workgroup owns 16 rows of G; in place: G -> V.
-/// Same workgroup -> (filter, row block) map as large_trsm_pipe (a filter's workgroups share one XCD).
-template <int NBMAX, int STAMP = 0>
-__global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<float> lv, t16::Planes pl, int nfilters, const int *skipped)
+namespace t16
 {
-        using namespace t16;
-        static_assert(NBMAX == 17, "the chain lists 17 block columns");
-        __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][BLK];
-        const int NP = lv.NP, nblk = NP / LB;
-        const int slot = blockIdx.x >> 3;
-        const int b = (slot / nblk) * 8 + (blockIdx.x & 7), rb = slot % nblk;
-        if (b >= nfilters || skipped[b])
-                return;
-        const int n = d.n[b];
-        const int nb = large_blocks(n);
-        if (rb >= nb)
-                return;
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        float *grow = lv.G + (size_t)b * NP * NP + (size_t)(LB * rb + 16 * wave + li) * NP + 4 * lg; // this lane's row of G (+ 4 lg): the stores of V
-        // The slices of G arrive by LDS-DMA like the blocks of L (four one-KiB pieces per wave and block column: its 16 rows x 64 columns, piece i =
-        // rows 4 i .. 4 i + 3, lane l = row l >> 4, 16-byte chunk l & 15), so that every load of the loop is counted by the same s_waitcnt vmcnt
-        // arithmetic: a load the compiler issues makes hipcc wait on ITS count of outstanding loads, which knows nothing of the DMA pieces in
-        // flight and drains them.
-        __shared__ __attribute__((aligned(1024))) float gl[4][16 * LB];
+/// what a sweep needs to know about the rows it solves: where they come from (a buffer resource + the byte offset of the wave's first row: the 16 x 64
+/// slices arrive by LDS-DMA), where the solved columns go in binary32 (this lane's row, + 4 lg), and -- Cholesky only -- where they go as bf16 planes
+struct Rows
+{
+        __amdgpu_buffer_rsrc_t rsrc; // the matrix the rows live in (G, or S for the Cholesky)
+        unsigned so0;                // byte offset of row 0 of this wave's 16 rows
+        float *out;                  // this lane's row, + 4 lg: the binary32 stores
+        __amdgpu_buffer_rsrc_t rq;   // CHOL: the filter's planes of L
+        unsigned vq;                 // CHOL: this lane's byte offset inside a plane (row, + 8 lg elements)
+        unsigned qplane;             // CHOL: bytes per plane
+};
+
+/// The sweep of one 16-row strip per wave over block columns 0 .. nbk - 1:  X(:, k) = (rows(:, k) - sum_{j<k} X(:, j) L(k, j)^T) Linv_k^T, kept in the
+/// strip and written out.  CHOL (large_chol_bf16: the rows are block row nbk of S itself): block column nbk follows -- its history blocks are
+/// L(nbk, j) = the X(:, j) this very sweep has just stored as planes, so every store is drained and the block pipeline restarted in front of them --
+/// and the sweep returns  c = S(nbk, nbk) - sum_j X(:, j) X(:, j)^T  (this wave's 16 rows: c[t][r] = column 16 t + 4 lg + r of row li) for the
+/// caller to factor.  `lds`: four block buffers; `gl`: this wave's 16 x 64 floats for the slices of the rows.
+template <int STAMP, bool CHOL>
+__device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsigned short (*lds)[BLK], float *gl, const Planes &pl, int b, int nbk, int nb_rows, int NP,
+                                        const Rows &rows, int tid)
+{
         typedef __attribute__((address_space(3))) float lds_f;
-        const __amdgpu_buffer_rsrc_t rgd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(lv.G + (size_t)b * NP * NP), 0, NP * NP * 4, 0x00020000);
+        typedef __attribute__((address_space(3))) unsigned short lds_us;
+        const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // The slices of the rows arrive by LDS-DMA like the blocks of L (four one-KiB pieces per wave and block column: its 16 rows x 64 columns,
+        // piece i = rows 4 i .. 4 i + 3, lane l = row l >> 4, 16-byte chunk l & 15), so that every load of the loop is counted by the same
+        // s_waitcnt vmcnt arithmetic: a load the compiler issues makes hipcc wait on ITS count of outstanding loads, which knows nothing of the
+        // DMA pieces in flight and drains them.
         const unsigned g_vo = (unsigned)(((lane >> 4) * NP + 4 * (lane & 15)) * 4);
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned g_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_f *)gl[wv]);
-        const unsigned g_so0 = (unsigned)((LB * rb + 16 * wv) * NP * 4), g_rs4 = (unsigned)(4 * NP * 4);
-        auto g_issue = [&](int kcol) { // this wave's 16 x 64 slice of block column kcol -> gl[wave]
+        const unsigned g_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_f *)gl);
+        const unsigned g_rs4 = (unsigned)(4 * NP * 4);
+        auto g_issue = [&](int kcol) { // this wave's 16 x 64 slice of block column kcol -> gl
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                         asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
                                      :
-                                     : "s"(g_lds), "n"(i * 1024), "v"(g_vo), "s"(rgd), "s"(g_so0 + (unsigned)i * g_rs4 + (unsigned)(LB * kcol * 4))
+                                     : "s"(g_lds), "n"(i * 1024), "v"(g_vo), "s"(rows.rsrc), "s"(rows.so0 + (unsigned)i * g_rs4 + (unsigned)(LB * kcol * 4))
                                      : "m0", "scc", "memory");
         };
         const int a_h0 = li * PLD + 8 * (lg ^ (li & 7)), a_h1 = li * PLD + 8 * ((4 + lg) ^ (li & 7)); // this lane's operand rows, half 0 / 1 (swizzled chunk)
-        asm volatile("" ::: "a0", "a255"); // the strip
-        Seq seq(pl, b, 0, nb, NP, tid);
-        Pipe pp;
-        pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3];
-        asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
-        // blocks 0, 1, 2 -> LDS
-        seq.issue(pp.b0);
-        seq.issue(pp.b1);
-        seq.issue(pp.b2);
-        g_issue(0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        Seq seq(pl, b, 0, nbk, NP, tid);
+        auto start = [&]() { // (re)start of the block pipeline at the block `seq` points at: blocks i, i + 1, i + 2 -> LDS; the caller waits and synchronises
+                pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3];
+                seq.issue(pp.b0);
+                seq.issue(pp.b1);
+                seq.issue(pp.b2);
+        };
+        if (!CHOL || nbk > 0)
+        {
+                start();
+                g_issue(0);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                load_planes(R.PA0, R.PA1, R.PA2, pp.b0, a_h0);
+                R.Pbh = R.Pbm = R.Pbl = (u4v){0u, 0u, 0u, 0u};
+        }
         if constexpr (STAMP)
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pp.tlast)::"memory");
-        Regs R;
-        load_planes(R.PA0, R.PA1, R.PA2, pp.b0, a_h0);
-        R.Pbh = R.Pbm = R.Pbl = (u4v){0u, 0u, 0u, 0u};
+        const int klast = CHOL ? nbk : nbk - 1;
 #pragma unroll 1
-        for (int k = 0; k < nb; ++k)
+        for (int k = 0; k <= klast; ++k)
         {
+                if (CHOL && k == nbk)
+                {
+                        // the history blocks of the diagonal block column are this workgroup's own output: every store has to have left the CU's memory
+                        // pipeline, and every wave has to be done with the LDS buffers, before the pipeline restarts on them
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        seq.k = nbk, seq.j = 0, seq.nb = nbk + 1, seq.diag = 1; // L(nbk, 0), ..., L(nbk, nbk - 1), then the last one again
+                        if (nbk > 0)
+                                start();
+                        g_issue(nbk);
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        if (nbk > 0)
+                        {
+                                load_planes(R.PA0, R.PA1, R.PA2, pp.b0, a_h0);
+                                float s8[8];
+                                strip_read8<0>(s8);
+                                split8(s8, R.Pbh, R.Pbm, R.Pbl);
+                        }
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                         R.run[i] = R.e[i] = R.o[i] = 0.f;
                 chain<0, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
-                // ---- closing block: C = G - history (running sum + the sums of the last history block, which no later block has added),
-                // X = C Linv_k^T (Linv is lower triangular in tiles: output tile t needs c tiles <= t).  Set P holds the first-half rows of Linv_k.
-                // this block column's slice of G: issued one block column ago; at most the six pieces of the last history block are younger
+                // ---- the closing block of column k: C = rows - history (running sum + the sums of the last history block, which no later block has
+                // added), X = C Linv_k^T (Linv is lower triangular in tiles: output tile t needs c tiles <= t).  Set P holds the first-half rows of
+                // Linv_k.  This column's slice of the rows was issued one block column ago: at most the six pieces of the last history block are younger.
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 f4 g0[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                        g0[t] = *reinterpret_cast<const f4 *>(&gl[wv][li * LB + 16 * t + 4 * lg]);
+                        g0[t] = *reinterpret_cast<const f4 *>(&gl[li * LB + 16 * t + 4 * lg]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                g_issue(min(k + 1, nb - 1)); // the next slice (ahead of this block's pieces of L: Pipe::end counts on that order)
+                if (!(CHOL && k == nbk))
+                        g_issue(CHOL ? k + 1 : min(k + 1, nbk - 1)); // the next slice (ahead of this block's pieces of L: Pipe::end counts on that order)
                 asm volatile("s_nop 15" : "+v"(R.e), "+v"(R.o)); // MFMA results -> VALU
                 {
                         const bool last_even = (k & 1) != 0; // history block k - 1
@@ -451,12 +480,20 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                                 for (int r = 0; r < 4; ++r)
                                         R.run[4 * t + r] = ct[r]; // C takes the place of the running sum
                         }
+                }
+                if (CHOL && k == nbk)
+                {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                                cdiag[t] = tile4(R.run, t); // (only here: a value written in every column would stay live through the regions)
+                        break;
+                }
+                {
                         const float c01[8] = {R.run[0], R.run[1], R.run[2], R.run[3], R.run[4], R.run[5], R.run[6], R.run[7]};
                         split8(c01, R.Pbh, R.Pbm, R.Pbl);
                 }
                 pp.template stamp<STAMP>(5);
                 {
-                        typedef __attribute__((address_space(3))) unsigned short lds_us;
                         const Dma dm = seq.next();
                         const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u));
                         const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1), a_nxt = (unsigned)(uintptr_t)(lds_us *)(pp.b1 + a_h0);
@@ -475,7 +512,22 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                         x[t] = tile4(R.e, t);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                        *reinterpret_cast<f4 *>(grow + LB * k + 16 * t) = x[t];
+                        *reinterpret_cast<f4 *>(rows.out + LB * k + 16 * t) = x[t];
+                if constexpr (CHOL)
+                {
+                        // the planes of L(nbk, k): row tiles 2 u and 2 u + 1 of a lane are eight consecutive positions of a permuted plane row
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                        {
+                                u2x h0, m0, l0, h1, m1, l1;
+                                split_bf16x3(x[2 * u], h0, m0, l0);
+                                split_bf16x3(x[2 * u + 1], h1, m1, l1);
+                                const int so = (LB * k + 32 * u) * 2;
+                                __builtin_amdgcn_raw_buffer_store_b128((u4v){h0[0], h0[1], h1[0], h1[1]}, rows.rq, (int)rows.vq, so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128((u4v){m0[0], m0[1], m1[0], m1[1]}, rows.rq, (int)rows.vq, so + (int)rows.qplane, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128((u4v){l0[0], l0[1], l1[0], l1[1]}, rows.rq, (int)rows.vq, so + 2 * (int)rows.qplane, 0);
+                        }
+                }
                 switch (k)
                 {
 #define ASLAM_T16_KEEP(K)                                                                                              \
@@ -512,11 +564,117 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
                 pp.template end<16>();
                 pp.template stamp<STAMP>(4);
         }
+        (void)nb_rows;
+}
+} // namespace t16
+
+/// V = G L^-T on the bf16 pipe.  grid (8 * ceil(B / 8) * NP / 64), 256 threads; wave w of a workgroup owns 16 rows of G; in place: G -> V.
+/// Same workgroup -> (filter, row block) map as large_trsm_pipe (a filter's workgroups share one XCD).
+template <int NBMAX, int STAMP = 0>
+__global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<float> lv, t16::Planes pl, int nfilters, const int *skipped)
+{
+        using namespace t16;
+        static_assert(NBMAX == 17, "the chain lists 17 block columns");
+        __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][BLK];
+        __shared__ __attribute__((aligned(1024))) float gl[4][16 * LB];
+        const int NP = lv.NP, nblk = NP / LB;
+        const int slot = blockIdx.x >> 3;
+        const int b = (slot / nblk) * 8 + (blockIdx.x & 7), rb = slot % nblk;
+        if (b >= nfilters || skipped[b])
+                return;
+        const int n = d.n[b];
+        const int nb = large_blocks(n);
+        if (rb >= nb)
+                return;
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        Rows rows;
+        rows.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(lv.G + (size_t)b * NP * NP), 0, NP * NP * 4, 0x00020000);
+        rows.so0 = (unsigned)((LB * rb + 16 * wv) * NP * 4);
+        rows.out = lv.G + (size_t)b * NP * NP + (size_t)(LB * rb + 16 * wave + li) * NP + 4 * lg;
+        rows.rq = rows.rsrc, rows.vq = 0, rows.qplane = 0;
+        asm volatile("" ::: "a0", "a255"); // the strip
+        Pipe pp;
+        Regs R;
+        f4 c[4];
+        asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
+        sweep16<STAMP, false>(c, R, pp, lds, gl[wv], pl, b, nb, nb, NP, rows, tid);
         asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
         if constexpr (STAMP)
                 if (tid == 0 && blockIdx.x == 0)
                         for (int i = 0; i < 9; ++i)
                                 lv.Y[i] = (double)pp.ph[i];
+}
+
+/// S = L L^T on the bf16 pipe: one workgroup per filter, block row after block row (large_chol_resident's structure, ekf_large_chol.h), every block
+/// row a sweep16<CHOL> over the planes of the block rows above it -- which this kernel writes as it goes (binary32 L and Linv are written too) --
+/// closed by the 64x64 factorisation of the diagonal block in binary64 tiles.  grid (B), 256 threads.  Status bit 4 (ASLAM_ST_NOT_PD) on a
+/// non-positive pivot.
+template <int NBMAX>
+__global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<float> lv, t16::Planes pl, const int *skipped)
+{
+        using namespace t16;
+        static_assert(NBMAX == 17, "the chain lists 17 block columns");
+        constexpr int PIPE_BYTES = NBUF * BLK * 2, TILE_BYTES = chol64::TILES * TSZ * (int)sizeof(double);
+        static_assert(TILE_BYTES <= PIPE_BYTES, "the tiles of the diagonal factorisation alias the block buffers");
+        __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][BLK];
+        __shared__ __attribute__((aligned(1024))) float gl[4][16 * LB];
+        double *tiles = reinterpret_cast<double *>(&lds[0][0]);
+        const int b = blockIdx.x;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        const int tid0 = threadIdx.x;
+        const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+        float *Sb = lv.S + (size_t)b * NP * NP;
+        float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
+        unsigned short *Liq = pl.Liq(b, NP);
+        asm volatile("" ::: "a0", "a255"); // the strip
+        Rows rows;
+        rows.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Sb), 0, NP * NP * 4, 0x00020000);
+        rows.rq = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(pl.Lq(b, NP)), 0, 3 * NP * NP * 2, 0x00020000);
+        rows.qplane = (unsigned)(NP * NP * 2);
+        bool ok = true;
+        Pipe pp;
+        Regs R;
+#pragma unroll 1
+        for (int I = 0; I < nb; ++I)
+        {
+                // one opaque re-definition of the thread index per block row: hipcc otherwise hoists every tid-derived address of the loop body out
+                // of the loop, runs out of VGPRs and parks the overflow in AGPRs -- the strip's (tools/check_agpr_strip.py)
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+                rows.so0 = (unsigned)((LB * I + 16 * wv) * NP * 4);
+                rows.out = Sb + (size_t)(LB * I + 16 * wave + li) * NP + 4 * lg;
+                rows.vq = (unsigned)(((LB * I + 16 * wave + li) * NP + 8 * lg) * 2);
+                f4 c[4];
+                asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
+                sweep16<0, true>(c, R, pp, lds, gl[wv], pl, b, I, nb, NP, rows, tid);
+                asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
+                // every DMA piece still in flight targets the buffers the tiles are about to take
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                // C (this wave's 16 rows: tile row `wave`) -> binary64 tiles, lower block triangle
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                {
+                        if (t <= wave)
+                        {
+                                double *T = chol64::Lt(tiles, wave, t) + li * TLD + 4 * lg;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        T[r] = (double)c[t][r];
+                        }
+                }
+                ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
+                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, Liq + (size_t)I * 3 * LB * LB);
+                // the next block row reads the planes back through the block pipeline
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+        }
+        if (!ok && tid0 == 0)
+                atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
 }
 
 /// L (lower block triangle of S after the factorisation) and Linv -> their bf16 planes (the form large_trsm_bf16 streams).  For the chains whose

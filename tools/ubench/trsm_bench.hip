@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "ekf_large.h"
@@ -169,7 +170,9 @@ int main(int argc, char **argv)
         }
         std::printf("large_trsm_pipe: max |V - host| / max |V| = %.2e (rows 0, 37, ... of filter %d)\n", worst / scale, B - 1);
         // ---- the bf16-pipe sweep (ekf_large_trsm16.h): planes of L from large_split_planes, then the same check
+        const char *only = std::getenv("ONLY"); // diagnostics: ONLY=trsm16 stops after this section, ONLY=chol16 skips it
         t16::Planes pl = {};
+        if (!(only && std::string(only) == "chol16"))
         {
                 CK(hipMalloc(&pl.base, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
                 CK(hipMemset(pl.base, 0, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
@@ -229,6 +232,8 @@ int main(int argc, char **argv)
                         stamps("second half: MFMAs only", large_trsm_bf16<LARGE_NB_MAX, 4>);
                 }
         }
+        if (only && std::string(only) == "trsm16")
+                return 0;
         // ---- timings (the result does not matter: G is solved again in place).  DIAG bits: 1 = no global fetch of the L blocks (stale
         // LDS), 2 = no LDS stash and no barrier, 16 = no barrier (racy), 8 = in-kernel stamps
         const double mfma_per_wave = 64.0 * 136 + 40.0 * 17;
@@ -321,6 +326,67 @@ int main(int argc, char **argv)
                         std::printf("  chol_resident writing the planes too, %d filters: %7.3f ms (the factor of a factor: timing only)\n", B, mc);
                         CK(hipFree(pa.base));
                         CK(hipFree(pb.base));
+                        reset_S();
+                }
+                {
+                        // ---- large_chol_bf16: the same factorisation on the bf16 pipe, writing L, Linv and their planes
+                        LPlanes pa = {}, pb = {};
+                        const size_t pe = LPlanes::per_filter(NP) * B;
+                        CK(hipMalloc(&pa.base, sizeof(unsigned short) * pe));
+                        CK(hipMalloc(&pb.base, sizeof(unsigned short) * pe));
+                        CK(hipMemset(pa.base, 0, sizeof(unsigned short) * pe));
+                        CK(hipMemset(pb.base, 0, sizeof(unsigned short) * pe));
+                        CK(hipMemset(dstatus, 0, sizeof(uint32_t) * B));
+                        hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lv, pa, dskip);
+                        hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
+                        CK(hipDeviceSynchronize());
+                        std::vector<float> L2(M), Li2((size_t)NB * LB * LB);
+                        std::vector<uint32_t> st2(B);
+                        CK(hipMemcpy(L2.data(), dS + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(Li2.data(), dLinv + (size_t)NB * LB * LB * (B - 1), sizeof(float) * NB * LB * LB, hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(st2.data(), dstatus, sizeof(uint32_t) * B, hipMemcpyDeviceToHost));
+                        double eL = 0, sL = 0;
+                        for (int i = 0; i < NP; ++i)
+                                for (int j = 0; j <= i; ++j)
+                                {
+                                        eL = std::fmax(eL, std::fabs((double)L2[(size_t)i * NP + j] - L[(size_t)i * NP + j]));
+                                        sL = std::fmax(sL, std::fabs(L[(size_t)i * NP + j]));
+                                }
+                        std::vector<unsigned short> ha(LPlanes::per_filter(NP)), hb(LPlanes::per_filter(NP));
+                        CK(hipMemcpy(ha.data(), pa.Lq(B - 1, NP), sizeof(unsigned short) * ha.size(), hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(hb.data(), pb.Lq(B - 1, NP), sizeof(unsigned short) * hb.size(), hipMemcpyDeviceToHost));
+                        size_t diff = 0;
+                        for (size_t i = 0; i < ha.size(); ++i)
+                                diff += ha[i] != hb[i];
+                        uint32_t anyst = 0;
+                        for (auto v : st2)
+                                anyst |= v;
+                        std::printf("large_chol_bf16: max |L - host| / max |L| = %.2e, status bits %u; its planes against large_split_planes of its L: %zu of %zu differ\n", eL / sL,
+                                    anyst, diff, ha.size());
+                        for (int bb : {15, 64, B})
+                        {
+                                if (bb > B)
+                                        break;
+                                reset_S();
+                                CK(hipDeviceSynchronize());
+                                hipEvent_t e0, e1;
+                                CK(hipEventCreate(&e0));
+                                CK(hipEventCreate(&e1));
+                                CK(hipEventRecord(e0));
+                                hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX>), dim3(bb), dim3(256), 0, 0, dc, lv, pa, dskip);
+                                CK(hipEventRecord(e1));
+                                CK(hipEventSynchronize(e1));
+                                float ms = 0;
+                                CK(hipEventElapsedTime(&ms, e0, e1));
+                                std::printf("  chol_bf16 %3d filters: %7.3f ms\n", bb, ms);
+                        }
+                        // and the bf16 TRSM on ITS planes
+                        reset_G();
+                        const float mt = time_ms([&]() { hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pa, B, dskip); }, 3);
+                        std::printf("  trsm_bf16 on the planes large_chol_bf16 wrote, %d filters: %7.3f ms\n", B, mt);
+                        CK(hipFree(pa.base));
+                        CK(hipFree(pb.base));
+                        CK(hipMemset(dstatus, 0, sizeof(uint32_t) * B));
                         reset_S();
                 }
                 hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lv, dskip);
