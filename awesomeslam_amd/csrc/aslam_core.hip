@@ -345,8 +345,12 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         }
                         hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
-                hipLaunchKernelGGL((large_x_update<T, MODE, sizeof(T) == 4>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses,
-                                   g.dims, g.skip);
+                if constexpr (sizeof(T) == 4)
+                        hipLaunchKernelGGL((large_x_update_rows<MODE>), dim3((NP + 4 * XU_ROWS - 1) / (4 * XU_ROWS), gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps,
+                                           g.poses, g.dims, g.skip);
+                else
+                        hipLaunchKernelGGL((large_x_update<T, MODE, false>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses, g.dims,
+                                           g.skip);
         };
         const int NG = c->large_groups;
         c->last_resident = (sizeof(T) == 4 && resident) ? 1 : 0;

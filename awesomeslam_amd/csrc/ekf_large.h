@@ -1260,6 +1260,82 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
                 }
         }
 }
+/// binary32 chain: X <- X + V q, and the diagonal + the three pose columns of V V^T in binary64 (see large_x_update<.., SLIM>), with the four rows
+/// every row of V is multiplied with -- q and the pose rows of V -- staged ONCE per workgroup in LDS (17 KB) for the XU_ROWS x 4 rows its waves
+/// walk.  With a wave per row and the shared rows read from memory every wave issued 25 loads of 16 bytes per lane for 4 KB of new data: 391 us
+/// per 256 filters against 217 us for round 2's single product (profiles/r03_experiments.md).  grid (ceil(NP / (4 XU_ROWS)), B), 256 threads.
+constexpr int XU_ROWS = 8;
+template <int MODE>
+__global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<float> lv, int s, int nsteps, double *poses_out, int32_t *dims_out, const int *skipped)
+{
+        __shared__ __attribute__((aligned(16))) float sh[4][LARGE_NP_MAX]; // q, pose rows 0 .. 2 of V
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int tid = threadIdx.x, lane = tid & 63;
+        if ((int)blockIdx.x * 4 * XU_ROWS >= n)
+                return;
+        const float *G = lv.G + (size_t)b * NP * NP;
+        for (int j = 4 * tid; j < NP; j += 4 * 256)
+        {
+                *reinterpret_cast<f4 *>(&sh[0][j]) = *reinterpret_cast<const f4 *>(G + (size_t)n * NP + j);
+                *reinterpret_cast<f4 *>(&sh[1][j]) = *reinterpret_cast<const f4 *>(G + j);
+                *reinterpret_cast<f4 *>(&sh[2][j]) = *reinterpret_cast<const f4 *>(G + NP + j);
+                *reinterpret_cast<f4 *>(&sh[3][j]) = *reinterpret_cast<const f4 *>(G + 2 * (size_t)NP + j);
+        }
+        __syncthreads();
+        double *P = lv.P + (size_t)b * NP * NP;
+        const int a0 = (blockIdx.x * 4 + (tid >> 6)) * XU_ROWS;
+#pragma unroll 1
+        for (int r = 0; r < XU_ROWS; ++r)
+        {
+                const int a = a0 + r;
+                if (a >= n)
+                        break; // wave-uniform
+                const float *vrow = G + (size_t)a * NP;
+                double acc = 0.0, dd = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+                for (int j = 4 * lane; j < n; j += 256) // (columns n .. of every row of V are zero)
+                {
+                        const f4 v = *reinterpret_cast<const f4 *>(vrow + j);
+                        const f4 wi = *reinterpret_cast<const f4 *>(&sh[0][j]), p0 = *reinterpret_cast<const f4 *>(&sh[1][j]),
+                                 p1 = *reinterpret_cast<const f4 *>(&sh[2][j]), p2 = *reinterpret_cast<const f4 *>(&sh[3][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                        {
+                                const double ve = (double)v[e];
+                                acc = fma(ve, (double)wi[e], acc);
+                                dd = fma(ve, ve, dd);
+                                d0 = fma(ve, (double)p0[e], d0);
+                                d1 = fma(ve, (double)p1[e], d1);
+                                d2 = fma(ve, (double)p2[e], d2);
+                        }
+                }
+                acc = wave_sum_dpp(acc), dd = wave_sum_dpp(dd), d0 = wave_sum_dpp(d0), d1 = wave_sum_dpp(d1), d2 = wave_sum_dpp(d2);
+                if (lane == 63)
+                {
+                        double *prow = P + (size_t)a * NP;
+                        const double dp[3] = {d0, d1, d2};
+                        // pose columns j < min(a, 3) with their mirror image; the diagonal entry itself
+                        for (int j = 0; j < 3 && j < a; ++j)
+                        {
+                                const double pn = prow[j] - dp[j];
+                                prow[j] = pn;
+                                P[(size_t)j * NP + a] = pn;
+                        }
+                        prow[a] -= dd;
+                        const double xa = d.X[(size_t)b * NP + a] + acc;
+                        d.X[(size_t)b * NP + a] = xa;
+                        if (MODE == MODE_REPLAY)
+                        {
+                                if (a < 3 && poses_out)
+                                        poses_out[((size_t)b * nsteps + s) * 3 + a] = xa;
+                                if (a == 0 && dims_out)
+                                        dims_out[(size_t)b * nsteps + s] = n;
+                        }
+                }
+        }
+}
 } // namespace aslam
 
 #include "ekf_large_trsm.h"
