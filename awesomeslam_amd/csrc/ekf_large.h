@@ -1287,23 +1287,44 @@ __global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<
         __syncthreads();
         double *P = lv.P + (size_t)b * NP * NP;
         const int a0 = (blockIdx.x * 4 + (tid >> 6)) * XU_ROWS;
+        constexpr int NPASS = 5; // 5 x 64 lanes x 4 columns = 1280 >= LARGE_NP_MAX
+        auto load_row = [&](f4 (&v)[NPASS], int a) {
+                const float *vr = G + (size_t)min(a, n - 1) * NP;
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i)
+                {
+                        const int j = 4 * lane + 256 * i;
+                        v[i] = j < n ? *reinterpret_cast<const f4 *>(vr + j) : (f4){0.f, 0.f, 0.f, 0.f}; // (columns n .. of every row of V are zero)
+                }
+        };
+        // the loads of row a + 1 are issued before row a is multiplied: the kernel lives on bytes in flight
+        f4 vn[NPASS];
+        load_row(vn, a0);
 #pragma unroll 1
         for (int r = 0; r < XU_ROWS; ++r)
         {
                 const int a = a0 + r;
                 if (a >= n)
                         break; // wave-uniform
-                const float *vrow = G + (size_t)a * NP;
+                f4 v[NPASS];
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i)
+                        v[i] = vn[i];
+                if (r + 1 < XU_ROWS)
+                        load_row(vn, a + 1);
                 double acc = 0.0, dd = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
-                for (int j = 4 * lane; j < n; j += 256) // (columns n .. of every row of V are zero)
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i)
                 {
-                        const f4 v = *reinterpret_cast<const f4 *>(vrow + j);
+                        const int j = 4 * lane + 256 * i;
+                        if (j >= n)
+                                continue; // (beyond NP nothing was staged)
                         const f4 wi = *reinterpret_cast<const f4 *>(&sh[0][j]), p0 = *reinterpret_cast<const f4 *>(&sh[1][j]),
                                  p1 = *reinterpret_cast<const f4 *>(&sh[2][j]), p2 = *reinterpret_cast<const f4 *>(&sh[3][j]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                         {
-                                const double ve = (double)v[e];
+                                const double ve = (double)v[i][e];
                                 acc = fma(ve, (double)wi[e], acc);
                                 dd = fma(ve, ve, dd);
                                 d0 = fma(ve, (double)p0[e], d0);
