@@ -62,10 +62,10 @@ def build(force=False, ukf=True):
     import time
 
     tools = os.path.join(_CSRC, "..", "..", "tools")
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
     srcs += [os.path.join(_CSRC, "host", f) for f in os.listdir(os.path.join(_CSRC, "host"))]
     srcs += [os.path.join(_CSRC, "Makefile"), os.path.join(_CSRC, "..", "..", "include", "aslam_core.h"),
-             os.path.join(tools, "check_spill_exec.py"), os.path.join(tools, "check_agpr_strip.py")]
+             os.path.join(tools, "check_spill_exec.py"), os.path.join(tools, "check_agpr_strip.py"), os.path.join(tools, "gen_trsm16_regions.py")]
     stale = force or not (os.path.exists(_CORE) and os.path.exists(_NODE)) or any(
         os.path.getmtime(s) > min(os.path.getmtime(_CORE), os.path.getmtime(_NODE)) for s in srcs)
     info_path = os.path.join(_CSRC, "build_info.json")

@@ -18,6 +18,7 @@
 
 #include "ekf_small.h"
 #include "ekf_large.h"
+#include "aslam_large16.h"
 #include "scan_front.h"
 #if ASLAM_HAVE_UKF
 #include "ukf_small.h"
@@ -75,6 +76,7 @@ struct aslam_ctx
         // chip that way, as 33 multi-workgroup launches (diagonal block + panel per block column) for few filters.
         // ASLAM_CHOL_RESIDENT=0/1 forces one form.
         int chol_resident = -1;
+        int bf16_pipe = 3;    // binary32 mode, resident Cholesky: Cholesky and TRSM on the bf16 matrix pipe (large_chol_bf16 + large_trsm_bf16, ekf_large_trsm16.h); ASLAM_BF16_PIPE=0: the fp32-MFMA kernels
         int syrk_running = 0; // diagnostic (ASLAM_SYRK_RUNNING=1): round 2's accumulation order in large_syrk_bf16x3 (profiles/r03_experiments.md)
         static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
         hipStream_t aux[LARGE_GROUPS - 1] = {};
@@ -306,6 +308,9 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 g.v.S += b * np * np;
                 g.v.Hc += b * (np / 2) * 4;
                 g.v.Linv += b * LARGE_NB_MAX * LB * LB;
+                if constexpr (sizeof(T) == 4)
+                        if (g.v.Lpl)
+                                g.v.Lpl += b * LPlanes::per_filter((int)np);
                 g.v.Y += b * np;
                 g.skip += b;
                 return g;
@@ -321,7 +326,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 {
                         // binary32: Cholesky of S alone (17 x {diagonal block, panel of S}), then V = G L^-T with the solved columns
                         // resident in registers (one launch), then P -= V V^T into the fp64 covariance
-                        if (resident)
+                        const bool pipe16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 1), chol16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 2);
+                        if (chol16)
+                                launch_chol_bf16(g.dv, g.v, gb, g.skip, g.st);
+                        else if (resident)
                                 hipLaunchKernelGGL(large_chol_resident<LARGE_NB_MAX>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                         else
                                 for (int k = 0; k < NB; ++k)
@@ -330,7 +338,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                         if (k + 1 < NB)
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
-                        hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                        if (pipe16)
+                                launch_trsm_bf16(g.dv, g.v, gb, g.skip, g.st);
+                        else
+                                hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         if (c->syrk_running)
                                 hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         else
@@ -520,6 +531,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         c->chol_resident = std::atoi(e) != 0;
                 if (const char *e = std::getenv("ASLAM_SYRK_RUNNING"))
                         c->syrk_running = std::atoi(e) != 0;
+                if (const char *e = std::getenv("ASLAM_BF16_PIPE"))
+                        c->bf16_pipe = std::atoi(e) & 3; // bit 0: the TRSM, bit 1: the Cholesky (diagnostics: 1 = large_chol_resident writes the planes, 2 = large_trsm_pipe solves)
                 for (hipStream_t &q : c->aux)
                         if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess)
                                 rc = ASLAM_ERR_HIP;
@@ -538,6 +551,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         A_(dev_alloc(c, &c->lv32.Hc, B * (NP / 2) * 4, c->owned));
                         A_(dev_alloc(c, &c->lv32.Y, B * NP, c->owned));
                         A_(dev_alloc(c, &c->lv32.Linv, B * LARGE_NB_MAX * LB * LB, c->owned));
+                        if (c->bf16_pipe)
+                                A_(dev_alloc(c, &c->lv32.Lpl, B * LPlanes::per_filter((int)NP), c->owned));
                 }
                 else
                 {
@@ -1212,7 +1227,9 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
         if (c->large)
         {
                 const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : c->cfg.batch >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
-                if (c->cfg.dtype == ASLAM_F32 && resident)
+                if (c->cfg.dtype == ASLAM_F32 && resident && c->lv32.Lpl)
+                        std::snprintf(buf, sizeof(buf), "large_chol_bf16 + large_trsm_bf16 + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)", c->large_groups);
+                else if (c->cfg.dtype == ASLAM_F32 && resident)
                         std::snprintf(buf, sizeof(buf), "large_chol_resident + large_trsm_pipe<%d> + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)",
                                       (int)LARGE_NB_MAX, c->large_groups);
                 else if (c->cfg.dtype == ASLAM_F32)

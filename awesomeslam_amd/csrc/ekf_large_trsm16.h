@@ -37,7 +37,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int PLD = LB;           // bf16 per LDS row
 constexpr int PLANE = LB * PLD;   // elements of one plane of a staged block
 constexpr int BLK = 3 * PLANE;    // a staged block: three planes, 24 576 bytes
-constexpr int NBUF = 4;           // LDS buffers: block i multiplied, i + 1 complete, i + 2 / i + 3 in flight
+constexpr int NBUF = 5;           // LDS buffers: block i multiplied, i + 1 complete (its first-half rows are read during block i), i + 2 landing, i + 3 / i + 4 in flight
 
 typedef LPlanes Planes; // (ekf_large.h)
 __host__ __device__ __forceinline__ int perm_pos(int c)
@@ -228,14 +228,17 @@ struct Seq
         }
 };
 
-/// Block pipeline over FOUR LDS buffers fed by LDS-DMA: block i is multiplied out of b0, block i + 1 is complete in b1 (its first operand rows are
-/// read behind the last MFMAs of block i), blocks i + 2 and i + 3 are in flight: the six pieces a wave moves of block i + 3 are issued INSIDE the
-/// regions of block i, between their MFMAs (issued together the 24 KB of a block keep the CU's one address unit busy for ~ 400 - 600 cycles), into
-/// the buffer block i - 1 left at the last barrier.  End of a block: every wave waits until at most the twelve youngest of its DMA pieces are
-/// outstanding -- its pieces of block i + 1 have landed (loads complete in order; a stricter count never hurts) -- and the barrier publishes block i + 1.
+/// Block pipeline over FIVE LDS buffers fed by LDS-DMA: block i is multiplied out of b0; block i + 1 must be COMPLETE in b1 throughout block i (its
+/// first-half operand rows are read behind the last MFMAs of block i); so at the end of block i every wave waits for its pieces of block i + 2 --
+/// at most the twelve youngest of its DMA pieces outstanding: blocks i + 3 and i + 4 (loads complete in order; a stricter count never hurts) -- and
+/// the barrier publishes block i + 2.  The six pieces a wave moves of block i + 4 are issued INSIDE the regions of block i, between their MFMAs
+/// (issued together the 24 KB of a block keep the CU's one address unit busy for ~ 400 - 600 cycles), into the buffer block i - 1 left at the last
+/// barrier.  (Round 3's first version had four buffers and the same counts: the first-half rows of the next block could be read before they had
+/// landed -- right on an idle chip, wrong with every CU busy; tools/ubench/trsm_bench.hip now compares all filters of a batch of identical inputs
+/// bit for bit.)
 struct Pipe
 {
-        unsigned short *b0, *b1, *b2, *b3;
+        unsigned short *b0, *b1, *b2, *b3, *b4;
         // diagnostic builds (STAMP): shader cycles by phase -- 0 first-half region, 1 between the halves, 2 second-half region, 3 end (barrier), 4 closing block
         unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0; // 5 .. 8: inside the closing block (C + split, first half, second half, stores + strip)
         template <int STAMP> __device__ __forceinline__ void stamp(int i)
@@ -248,7 +251,7 @@ struct Pipe
                         tlast = t;
                 }
         }
-        /// LATER: loads issued after this wave's pieces of block i + 1 (two blocks' pieces = 12; 16 in the closing block and in the block after it, which
+        /// LATER: loads issued after this wave's pieces of block i + 2 (two blocks' pieces = 12; 16 in the closing block and in the block after it, which
         /// have the four loads of the next slice of G in between; the stores of V only make the wait stricter)
         template <int LATER = 12> __device__ __forceinline__ void end()
         {
@@ -261,7 +264,8 @@ struct Pipe
                 b0 = b1;
                 b1 = b2;
                 b2 = b3;
-                b3 = t;
+                b3 = b4;
+                b4 = t;
         }
 };
 
@@ -298,7 +302,7 @@ template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &
 {
         typedef __attribute__((address_space(3))) unsigned short lds_us;
         const Dma dm = seq.next();
-        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u));
+        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b4 + (unsigned)seq.wave * 1024u));
         const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1); // the second half of this block
         if constexpr (J == 0)
                 asm volatile(ASLAM_T16_H0_E : "=&{v[32:47]}"(R.e), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 16 * J + 8, 0) : ASLAM_T16_SCRATCH);
@@ -397,7 +401,6 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
         typedef __attribute__((address_space(3))) float lds_f;
         typedef __attribute__((address_space(3))) unsigned short lds_us;
         const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         // The slices of the rows arrive by LDS-DMA like the blocks of L (four one-KiB pieces per wave and block column: its 16 rows x 64 columns,
         // piece i = rows 4 i .. 4 i + 3, lane l = row l >> 4, 16-byte chunk l & 15), so that every load of the loop is counted by the same
         // s_waitcnt vmcnt arithmetic: a load the compiler issues makes hipcc wait on ITS count of outstanding loads, which knows nothing of the
@@ -415,11 +418,12 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
         };
         const int a_h0 = li * PLD + 8 * (lg ^ (li & 7)), a_h1 = li * PLD + 8 * ((4 + lg) ^ (li & 7)); // this lane's operand rows, half 0 / 1 (swizzled chunk)
         Seq seq(pl, b, 0, nbk, NP, tid);
-        auto start = [&]() { // (re)start of the block pipeline at the block `seq` points at: blocks i, i + 1, i + 2 -> LDS; the caller waits and synchronises
-                pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3];
+        auto start = [&]() { // (re)start of the block pipeline at the block `seq` points at: blocks i .. i + 3 -> LDS; the caller waits and synchronises
+                pp.b0 = lds[0], pp.b1 = lds[1], pp.b2 = lds[2], pp.b3 = lds[3], pp.b4 = lds[4];
                 seq.issue(pp.b0);
                 seq.issue(pp.b1);
                 seq.issue(pp.b2);
+                seq.issue(pp.b3);
         };
         if (!CHOL || nbk > 0)
         {
@@ -495,7 +499,7 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                 pp.template stamp<STAMP>(5);
                 {
                         const Dma dm = seq.next();
-                        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b3 + (unsigned)seq.wave * 1024u));
+                        const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)pp.b4 + (unsigned)seq.wave * 1024u));
                         const unsigned a_cur = (unsigned)(uintptr_t)(lds_us *)(pp.b0 + a_h1), a_nxt = (unsigned)(uintptr_t)(lds_us *)(pp.b1 + a_h0);
                         // first half; behind it C tiles 2, 3 are split (-> set Q) and the second-half rows of Linv_k are read
                         asm volatile(ASLAM_T16_C0 : "=&{v[32:47]}"(R.e), "+{v[64:79]}"(R.run), ASLAM_T16_Q_OUT : ASLAM_T16_P_IN, ASLAM_T16_COMMON(a_cur, 0, 0) : ASLAM_T16_SCRATCH);
@@ -680,6 +684,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<f
 /// L (lower block triangle of S after the factorisation) and Linv -> their bf16 planes (the form large_trsm_bf16 streams).  For the chains whose
 /// Cholesky kernels still write binary32 (the multi-workgroup chain of small batches; the fp32-MFMA resident Cholesky).  grid (NP / 64 + 1, B),
 /// 256 threads: workgroup x < NP / 64 splits block row x of L (blocks j < x), workgroup NP / 64 the inverses of the diagonal blocks.
+template <int UNUSED = 0> // (a template: the header is included by both translation units of the library)
 __global__ __launch_bounds__(256) void large_split_planes(DevView d, LargeView<float> lv, t16::Planes pl, const int *skipped)
 {
         using namespace t16;

@@ -47,7 +47,15 @@ PEAK_F64_TFLOPS = 78.6
 # peak (2.5 PFLOP/s, 16 cycles per 16x16x32 instruction) / 6 = fp32-equivalent FLOP/s; tools/ubench/mfma_bf16x3.hip measures 308 T
 PEAK_BF16X3_TFLOPS = 2516.6 / 6.0
 # which pipe each third of the chain's 2.33 n^3 runs on (fractions of n^3): Cholesky of S, V = G L^-T, P -= V V^T
-EKF512_PIPES = {"chol": (1.0 / 3.0, "fp32"), "trsm": (1.0, "fp32"), "syrk": (1.0, "bf16x3")}
+# (the library's kernel_info names the kernels of the chain it launches: `large_chol_bf16` / `large_trsm_bf16` are the bf16x3 forms)
+EKF512_FLOPS_N3 = {"chol": 1.0 / 3.0, "trsm": 1.0, "syrk": 1.0}
+
+
+def ekf512_pipes(kernel_name):
+    pipe = lambda bf: "bf16x3" if bf else "fp32"
+    return {"chol": (EKF512_FLOPS_N3["chol"], pipe("large_chol_bf16" in kernel_name)),
+            "trsm": (EKF512_FLOPS_N3["trsm"], pipe("large_trsm_bf16" in kernel_name)),
+            "syrk": (EKF512_FLOPS_N3["syrk"], pipe("large_syrk_bf16x3" in kernel_name))}
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s peak (about 6.3 TB/s achievable)
 UKF_MAX_CALLBACKS = 3000  # the reference UKF stays positive definite for a few thousand callbacks at n = 131
 PROLOGUE = 64  # callbacks: the 42-callback warm-up in which the state grows to its full dimension, rounded up
@@ -365,7 +373,7 @@ def parity_check(workload, ids, tr, finals, T, local):
                        "p_rel_err norm-wise, p_block_rel_err the worst of the pose 3x3, pose-landmark and landmark blocks, each against its own maximum"}
 
 
-def roofline(workload, B, C, kernel_s):
+def roofline(workload, B, C, kernel_s, kernel_name=""):
     from awesomeslam_amd import trace as tg
 
     kind, L, _ = WORKLOADS[workload]
@@ -389,10 +397,11 @@ def roofline(workload, B, C, kernel_s):
     if large:
         # ADVICE / VERDICT round 2: `frac` divides fp32-equivalent flops by the fp32 MFMA peak although part of them runs on the (faster) bf16
         # pipe.  mixed_pipe_frac = the time the algorithmic flops would take at the peak of the pipe each part really uses / the measured time.
-        t_ideal = sum(f * n ** 3 / ((PEAK_F32_TFLOPS if pipe == "fp32" else PEAK_BF16X3_TFLOPS) * 1e12) for f, pipe in EKF512_PIPES.values())
+        pipes = ekf512_pipes(kernel_name)
+        t_ideal = sum(f * n ** 3 / ((PEAK_F32_TFLOPS if pipe == "fp32" else PEAK_BF16X3_TFLOPS) * 1e12) for f, pipe in pipes.values())
         mixed = {"frac": t_ideal * B * C / kernel_s, "fp32_equivalent": True,
                  "pipes": {k: {"flops_n3": f, "pipe": pipe, "peak_tflops": PEAK_F32_TFLOPS if pipe == "fp32" else PEAK_BF16X3_TFLOPS}
-                           for k, (f, pipe) in EKF512_PIPES.items()},
+                           for k, (f, pipe) in pipes.items()},
                  "note": "time of the 2.33 n^3 algorithmic flops at the peaks of the pipes they run on (fp32 MFMA 157.3 T; bf16x3 = dense bf16 "
                          "peak / 6 = 419 T fp32-equivalent, 308 T measured by tools/ubench/mfma_bf16x3.hip) / measured launch time"}
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -406,7 +415,7 @@ def roofline(workload, B, C, kernel_s):
                     "launch stream); executed_frac = the same with the flops the kernels really issue (padded tiles; the single-CU EKF "
                     "update needs only S^-1 since R = r I: about n^3); peak = dense " + ("fp32" if large else "fp64")
                     + " MFMA rate (MI355X_MICROARCH.md); traffic = PMC bytes at the L2's memory side (profiles/pmc_traffic.json)"
-                    + ("; the n^3 flops of P -= V V^T (of the 2.33 n^3) are binary32 products formed on the bf16 matrix pipe -- every float split "
+                    + ("; the products of the kernels mixed_pipe lists as bf16x3 (all 2.33 n^3 with the default chain) are binary32 products formed on the bf16 matrix pipe -- every float split "
                        "exactly into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per 16x16x32 product, fp32 accumulation: twice the fp32 MFMA "
                        "rate at a smaller error (tools/ubench/mfma_bf16x3.hip) -- and are counted as the fp32 flops they replace; the peak stays the "
                        "fp32 MFMA figure the path's arithmetic type names" if large else "")}
@@ -481,7 +490,7 @@ def main():
                        "parallelism": f"trajectory-sharded x{world}",
                        "kernel": info["name"], "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"],
                        "trace_gen_s": round(t_gen, 1)},
-            "roofline": roofline(wl, B, C, kernel_s),
+            "roofline": roofline(wl, B, C, kernel_s, info["name"]),
         }
         if info.get("launch"):
             out["config"]["launch"] = info["launch"]

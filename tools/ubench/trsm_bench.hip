@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
@@ -176,7 +177,7 @@ int main(int argc, char **argv)
         {
                 CK(hipMalloc(&pl.base, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
                 CK(hipMemset(pl.base, 0, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
-                const float msp = time_ms([&]() { hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pl, dskip); }, 3);
+                const float msp = time_ms([&]() { hipLaunchKernelGGL(large_split_planes<0>, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pl, dskip); }, 3);
                 reset_G();
                 hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, B, dskip);
                 CK(hipDeviceSynchronize());
@@ -309,7 +310,7 @@ int main(int argc, char **argv)
                         CK(hipMemset(pb.base, 0, sizeof(unsigned short) * pe));
                         lp.Lpl = pa.base;
                         hipLaunchKernelGGL((large_chol_resident<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lp, dskip);
-                        hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
+                        hipLaunchKernelGGL(large_split_planes<0>, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
                         CK(hipDeviceSynchronize());
                         std::vector<unsigned short> ha(LPlanes::per_filter(NP)), hb(LPlanes::per_filter(NP));
                         CK(hipMemcpy(ha.data(), pa.Lq(B - 1, NP), sizeof(unsigned short) * ha.size(), hipMemcpyDeviceToHost));
@@ -338,7 +339,7 @@ int main(int argc, char **argv)
                         CK(hipMemset(pb.base, 0, sizeof(unsigned short) * pe));
                         CK(hipMemset(dstatus, 0, sizeof(uint32_t) * B));
                         hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX>), dim3(B), dim3(256), 0, 0, dc, lv, pa, dskip);
-                        hipLaunchKernelGGL(large_split_planes, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
+                        hipLaunchKernelGGL(large_split_planes<0>, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pb, dskip);
                         CK(hipDeviceSynchronize());
                         std::vector<float> L2(M), Li2((size_t)NB * LB * LB);
                         std::vector<uint32_t> st2(B);
@@ -363,6 +364,32 @@ int main(int argc, char **argv)
                                 anyst |= v;
                         std::printf("large_chol_bf16: max |L - host| / max |L| = %.2e, status bits %u; its planes against large_split_planes of its L: %zu of %zu differ\n", eL / sL,
                                     anyst, diff, ha.size());
+                        {
+                                // every filter has the same input: every filter's L must be bit-identical to filter 0's -- a race detector
+                                std::vector<float> L0(M), Lb(M);
+                                CK(hipMemcpy(L0.data(), dS, sizeof(float) * M, hipMemcpyDeviceToHost));
+                                int bad = 0, firstb = -1;
+                                size_t firsti = 0, nbad0 = 0;
+                                for (int b = 1; b < B; ++b)
+                                {
+                                        CK(hipMemcpy(Lb.data(), dS + M * b, sizeof(float) * M, hipMemcpyDeviceToHost));
+                                        size_t nb_ = 0, fi = 0;
+                                        for (int i = 0; i < NP; ++i)
+                                                for (int j = 0; j <= i; ++j)
+                                                        if (std::memcmp(&Lb[(size_t)i * NP + j], &L0[(size_t)i * NP + j], 4) && !nb_++)
+                                                                fi = (size_t)i * NP + j;
+                                        if (nb_)
+                                        {
+                                                if (!bad++)
+                                                        firstb = b, firsti = fi, nbad0 = nb_;
+                                        }
+                                }
+                                std::printf("large_chol_bf16: %d of %d filters differ from filter 0 in L (identical inputs)", bad, B - 1);
+                                if (bad)
+                                        std::printf("; first: filter %d, %zu entries, first at row %zu column %zu (block %zu, %zu)", firstb, nbad0, firsti / NP, firsti % NP, firsti / NP / 64,
+                                                    firsti % NP / 64);
+                                std::printf("\n");
+                        }
                         for (int bb : {15, 64, B})
                         {
                                 if (bb > B)
