@@ -107,16 +107,18 @@ __device__ __forceinline__ void split_bf16x3(const f4 &x, u2x &h, u2x &m, u2x &l
         }
 }
 
-/// Planes of L in HBM (binary32 mode; written by large_chol_resident, streamed by large_trsm_bf16 -- ekf_large_trsm16.h), one allocation, per
-/// filter: Lq [3][NP][NP] bf16 (row-major, columns permuted inside every 64-block; only blocks below the diagonal are read) followed by Liq
-/// [LARGE_NB_MAX][3][64][64] bf16 (the inverses of the diagonal blocks, columns permuted the same way): one buffer resource per filter serves both.
+/// Planes of L in HBM (binary32 mode; written by the resident Cholesky kernels, streamed by large_trsm_bf16 / large_chol_bf16 --
+/// ekf_large_trsm16.h), per filter: Lq [3][NP][NP] bf16, row-major, columns permuted inside every 64-block.  Block (k, j), j < k, holds L(k, j);
+/// the DIAGONAL block (k, k) holds the INVERSE of L(k, k) -- the sweeps multiply by it and never read L(k, k) itself -- so that every block of a
+/// sweep's sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ...  has the same row / plane strides and its address is one multiply-add
+/// (the round's first layout kept the inverses behind the planes: 40 scalar instructions and three branches per block to pick the layout).
 struct LPlanes
 {
         unsigned short *base;
-        __host__ __device__ static size_t lq_elems(int NP) { return (size_t)3 * NP * NP; }
-        __host__ __device__ static size_t per_filter(int NP) { return lq_elems(NP) + (size_t)(1088 / 64) * 3 * 64 * 64; }
+        __host__ __device__ static size_t per_filter(int NP) { return (size_t)3 * NP * NP; }
         __host__ __device__ unsigned short *Lq(int b, int NP) const { return base + (size_t)b * per_filter(NP); }
-        __host__ __device__ unsigned short *Liq(int b, int NP) const { return Lq(b, NP) + lq_elems(NP); }
+        /// plane 0 of block (k, j) (row stride NP, plane stride NP * NP)
+        __host__ __device__ unsigned short *block(int b, int NP, int k, int j) const { return Lq(b, NP) + (size_t)(64 * k) * NP + 64 * j; }
 };
 /// position of column c (0 .. 63) of a block inside a permuted plane row: 32 h + 8 g + 4 w + r holds column 32 h + 16 w + 4 g + r
 __host__ __device__ __forceinline__ int lplane_pos(int c)

@@ -174,7 +174,8 @@ template <bool F32_DIAG> __device__ __forceinline__ bool factor_and_invert(doubl
 
 /// L (zeros above the diagonal) -> the 64x64 block at `Sdiag` (row stride NP), Linv = R^T -> `Linv_out` [64][64]: thread = row r, 16-column
 /// segment q.  T = float or double.
-/// `Liq` (binary32 only, may be null): the inverse ALSO as three bf16 planes [3][64][64] with permuted columns (LPlanes, ekf_large.h): the thread's
+/// `Liq` (binary32 only, may be null): the inverse ALSO as three bf16 planes with permuted columns, at the diagonal block's place in the planes of L
+/// (LPlanes, ekf_large.h: `Liq` = plane 0 of that block, row stride NP, plane stride NP * NP): the thread's
 /// columns 16 q + 4 g .. + 3 go to positions 32 (q >> 1) + 8 g + 4 (q & 1) .. + 3.
 template <typename T> __device__ __forceinline__ void store_block(const double *t, T *Sdiag, int NP, T *Linv_out, int tid, unsigned short *Liq = nullptr)
 {
@@ -200,10 +201,10 @@ template <typename T> __device__ __forceinline__ void store_block(const double *
                         {
                                 u2x h, m, l;
                                 split_bf16x3((f4){(float)inv[4 * g], (float)inv[4 * g + 1], (float)inv[4 * g + 2], (float)inv[4 * g + 3]}, h, m, l);
-                                unsigned short *dst = Liq + r * LB + 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                                unsigned short *dst = Liq + (size_t)r * NP + 32 * (q >> 1) + 8 * g + 4 * (q & 1);
                                 *reinterpret_cast<u2x *>(dst) = h;
-                                *reinterpret_cast<u2x *>(dst + LB * LB) = m;
-                                *reinterpret_cast<u2x *>(dst + 2 * LB * LB) = l;
+                                *reinterpret_cast<u2x *>(dst + (size_t)NP * NP) = m;
+                                *reinterpret_cast<u2x *>(dst + 2 * (size_t)NP * NP) = l;
                         }
                 }
         }
@@ -273,7 +274,6 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
         const unsigned qplane = lv.Lpl ? (unsigned)(NP * NP * 2) : 0u;
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(lv.Lpl ? lpl.Lq(b, NP) : reinterpret_cast<unsigned short *>(Sb), 0, 3 * NP * NP * 2, 0x00020000);
         const unsigned vq0 = (unsigned)(((16 * wave + li) * NP + 8 * lg) * 2); // this lane's row inside a block row, + 8 lg elements
-        unsigned short *Liq = lv.Lpl ? lpl.Liq(b, NP) : nullptr;
         bool ok = true;
         // STAMP (diagnostic build, tools/ubench/trsm_bench.hip): shader cycles of workgroup 0 by phase -> lv.Y[0 .. 3]: sweeps, conversion, diagonal
         // factorisation, stores + drain
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_resident(DevView d, LargeVi
                 ASLAM_PH(1)
                 ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
                 ASLAM_PH(2)
-                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, Liq ? Liq + (size_t)I * 3 * LB * LB : nullptr);
+                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, lv.Lpl ? lpl.block(b, NP, I, I) : nullptr);
                 // the next block row reads them back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();

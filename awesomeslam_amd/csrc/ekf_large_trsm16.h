@@ -169,46 +169,44 @@ template <typename T> __device__ __forceinline__ T *uniform_ptr(T *p)
 }
 
 /// One block's LDS-DMA descriptor: the regions issue its six one-KiB pieces per wave (piece i: plane i >> 1, rows 8 (4 (i & 1) + wave) .. + 7 of the
-/// block; lane l = row l >> 3 of the piece, the 16 bytes that belong at chunk position l & 7 of that row: logical chunk (l & 7) ^ (l >> 3))
+/// block; lane l = row l >> 3 of the piece, the 16 bytes that belong at chunk position l & 7 of that row: logical chunk (l & 7) ^ (l >> 3)).  Every
+/// block of the planes has the same strides (LPlanes), so a lane's six byte offsets inside a block are constants of the kernel and a block is ONE
+/// scalar: the byte offset of its first element.
 struct Dma
 {
-        __amdgpu_buffer_rsrc_t rsrc; // the filter's planes of L, or of the inverses of its diagonal blocks
-        unsigned voff;               // this lane's byte offset inside a piece
-        unsigned so[6];              // byte offsets of the six pieces
+        __amdgpu_buffer_rsrc_t rsrc; // the filter's planes
+        unsigned so;                 // byte offset of the block
+        unsigned v0, v1, v2, v3, v4, v5; // this lane's byte offsets of the six pieces inside a block
 };
 
-/// cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ... (as TrsmSeq) on the planes.  Scalar state only.
+/// cursor over the block sequence  Linv_0; L(1,0), Linv_1; L(2,0), L(2,1), Linv_2; ... (as TrsmSeq) on the planes = blocks (k, 0 .. k), k = 0 .. nb - 1.
+/// Scalar state only (and the six lane offsets).
 struct Seq
 {
         int k, j, nb, NP, wave;
         int diag = 0; // Cholesky, diagonal block column: only the history blocks L(k, 0 .. k-1) exist -- the inverse of block k is written AFTER this
                       // sweep, and a prefetch of it now would leave a stale copy in the CU's L1 for the next block row to hit
-        __amdgpu_buffer_rsrc_t rs; // the filter's planes: L, then the inverses (Planes)
-        unsigned inv0;             // byte offset of the inverses
-        unsigned vo_l, vo_i;
+        __amdgpu_buffer_rsrc_t rs; // the filter's planes
+        unsigned v0, v1, v2, v3, v4, v5;
         __device__ __forceinline__ Seq(const Planes &pl, int b, int k0, int nb_, int NP_, int tid)
             : k(k0), j(0), nb(nb_), NP(NP_), wave(__builtin_amdgcn_readfirstlane(tid >> 6)),
-              rs(__builtin_amdgcn_make_buffer_rsrc(uniform_ptr(pl.Lq(b, NP_)), 0, (int)(Planes::per_filter(NP_) * 2), 0x00020000)), inv0((unsigned)(Planes::lq_elems(NP_) * 2))
+              rs(__builtin_amdgcn_make_buffer_rsrc(uniform_ptr(pl.Lq(b, NP_)), 0, (int)(Planes::per_filter(NP_) * 2), 0x00020000))
         {
                 const int l = tid & 63, r = l >> 3, lc = (l & 7) ^ r;
-                vo_l = (unsigned)((r * NP_ + 8 * lc) * 2);
-                vo_i = (unsigned)((r * LB + 8 * lc) * 2);
+                const unsigned ps = (unsigned)(NP_ * NP_ * 2), r8 = (unsigned)(8 * NP_ * 2);
+                v0 = (unsigned)((r * NP_ + 8 * lc) * 2) + (unsigned)(tid >> 6) * r8;
+                v1 = v0 + 4u * r8, v2 = v0 + ps, v3 = v1 + ps, v4 = v2 + ps, v5 = v3 + ps;
         }
         /// the next block of the sequence
         __device__ __forceinline__ Dma next()
         {
                 if (diag && j >= k)
                         j = max(k - 1, 0); // (past the end of the diagonal column's history: the last block again)
-                const bool hist = j < k;
                 Dma dm;
                 dm.rsrc = rs;
-                dm.voff = hist ? vo_l : vo_i;
-                const unsigned base = hist ? (unsigned)(((LB * k) * NP + LB * j) * 2) : inv0 + (unsigned)(k * 3 * LB * LB * 2);
-                // piece i: plane i >> 1, rows 8 (4 (i & 1) + wave) ..  (no arrays in this struct: hipcc moves a struct with selected-between arrays to LDS)
-                const unsigned ps = hist ? (unsigned)(NP * NP * 2) : (unsigned)(LB * LB * 2), r8 = hist ? (unsigned)(8 * NP * 2) : (unsigned)(8 * LB * 2);
-                const unsigned w0 = base + (unsigned)wave * r8, w1 = w0 + 4u * r8;
-                dm.so[0] = w0, dm.so[1] = w1, dm.so[2] = w0 + ps, dm.so[3] = w1 + ps, dm.so[4] = w0 + 2u * ps, dm.so[5] = w1 + 2u * ps;
-                const bool adv = !hist && k + 1 < nb;
+                dm.v0 = v0, dm.v1 = v1, dm.v2 = v2, dm.v3 = v3, dm.v4 = v4, dm.v5 = v5;
+                dm.so = (unsigned)(((LB * k) * NP + LB * j) * 2);
+                const bool hist = j < k, adv = !hist && k + 1 < nb;
                 j = hist ? j + 1 : (adv ? 0 : j);
                 k += adv ? 1 : 0;
                 return dm;
@@ -219,11 +217,13 @@ struct Seq
                 typedef __attribute__((address_space(3))) unsigned short lds_us;
                 const Dma dm = next();
                 const unsigned ldsw = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)dst + (unsigned)wave * 1024u));
+                const unsigned vo[6] = {dm.v0, dm.v1, dm.v2, dm.v3, dm.v4, dm.v5};
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)dm.so); // (wave-uniform, but hipcc may have formed it in a vector register)
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %3 offen lds"
                                      :
-                                     : "s"(ldsw), "n"((i >> 1) * 8192 + (i & 1) * 4096), "v"(dm.voff), "s"(dm.rsrc), "s"(dm.so[i])
+                                     : "s"(ldsw), "n"((i >> 1) * 8192 + (i & 1) * 4096), "v"(vo[i]), "s"(so), "s"(dm.rsrc)
                                      : "m0", "scc", "memory");
         }
 };
@@ -240,7 +240,7 @@ struct Pipe
 {
         unsigned short *b0, *b1, *b2, *b3, *b4;
         // diagnostic builds (STAMP): shader cycles by phase -- 0 first-half region, 1 between the halves, 2 second-half region, 3 end (barrier), 4 closing block
-        unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0; // 5 .. 8: inside the closing block (C + split, first half, second half, stores + strip)
+        unsigned long long ph[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0; // 5 .. 8: inside the closing block (C + split, first half, second half, strip write); 9 .. 12: the wait for the slice of the rows, its LDS reads + the issue of the next slice, the stores, the vmcnt wait at the end
         template <int STAMP> __device__ __forceinline__ void stamp(int i)
         {
                 if constexpr (STAMP)
@@ -251,15 +251,14 @@ struct Pipe
                         tlast = t;
                 }
         }
-        /// LATER: loads issued after this wave's pieces of block i + 2 (two blocks' pieces = 12; 16 in the closing block and in the block after it, which
-        /// have the four loads of the next slice of G in between; the stores of V only make the wait stricter)
+        /// LATER: vector-memory instructions this wave has issued after its pieces of block i + 2 -- two blocks' pieces = 12, plus, around a closing
+        /// block, the four loads of the next slice of G and the closing block's S stores (4 of V; the Cholesky's 6 plane stores on top): loads and
+        /// stores retire in issue order on this counter, so counting the stores keeps the wait from covering pieces issued only one block ago
+        /// (with 16 the closing block stood ~ 770 cycles at this wait: tools/ubench/trsm_bench.hip, phase stamps).
         template <int LATER = 12> __device__ __forceinline__ void end()
         {
-                static_assert(LATER == 12 || LATER == 16, "vmcnt count");
-                if constexpr (LATER == 12)
-                        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-                else
-                        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                static_assert(LATER >= 12 && LATER <= 63, "vmcnt count");
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LATER) : "memory");
                 unsigned short *t = b0;
                 b0 = b1;
                 b1 = b2;
@@ -291,14 +290,16 @@ struct Regs
 #define ASLAM_T16_Q_IN "{v[160:175]}"(R.QA0), "{v[176:191]}"(R.QA1), "{v[192:207]}"(R.QA2), "{v[208:211]}"(R.Qbh), "{v[212:215]}"(R.Qbm), "{v[216:219]}"(R.Qbl)
 /// operands every region takes: the LDS address of the operand rows it reads, the bf16 mask, the first strip register of the B operand it prepares,
 /// and the LDS-DMA pieces it issues (pieces H .. H + 2 of descriptor dm into the buffer at LDS address ldsw)
-#define ASLAM_T16_COMMON(addr, R0, H) [lds] "v"(addr), [msk] "s"(0xffff0000u), [r0] "n"(R0), [ldsw] "s"(ldsw), [voff] "v"(dm.voff), [rsrc] "s"(dm.rsrc), [so0] "s"(dm.so[H]), [so1] "s"(dm.so[H + 1]), [so2] "s"(dm.so[H + 2])
+#define ASLAM_T16_VO0 [vo0] "v"(dm.v0), [vo1] "v"(dm.v1), [vo2] "v"(dm.v2)
+#define ASLAM_T16_VO3 [vo0] "v"(dm.v3), [vo1] "v"(dm.v4), [vo2] "v"(dm.v5)
+#define ASLAM_T16_COMMON(addr, R0, H) [lds] "v"(addr), [msk] "s"(0xffff0000u), [r0] "n"(R0), [ldsw] "s"(ldsw), [rsrc] "s"(dm.rsrc), [so] "s"(dm.so), ASLAM_T16_VO##H
 
 /// One history block J (even J: sums in R.e, odd J: in R.o), set P holding the operands of its first half on entry and of the NEXT block's first half
 /// on exit.  Inside the MFMA gaps of the first half: the strip registers of the second half are read and split, its operand rows are read from LDS
 /// (-> set Q), and the finished sums of the previous block are added to the column's running sum; inside those of the second half: the same for the
 /// first half of the next block in the stream (history block J + 1 of this column, whose operand rows are in b1 -- or the closing block, whose B
 /// operand is not a strip tile: that split is wasted).  Both halves carry three of the six DMA pieces of the block three ahead.
-template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &R, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
+template <int J, int STAMP, int NST> __device__ __forceinline__ void history_block(Regs &R, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
 {
         typedef __attribute__((address_space(3))) unsigned short lds_us;
         const Dma dm = seq.next();
@@ -324,6 +325,8 @@ template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &
                 asm volatile(ASLAM_T16_H1_E_NOVALU : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
         else if constexpr (STAMP == 3)
                 asm volatile(ASLAM_T16_H1_E_NODS : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
+        else if constexpr (STAMP == 5) // (the block's pieces 3 .. 5 are never fetched: timing only)
+                asm volatile(ASLAM_T16_H1_E_NODMA : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
         else if constexpr (STAMP == 4)
                 asm volatile(ASLAM_T16_H1_E_BARE : "+{v[32:47]}"(R.e), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
         else if constexpr (J % 2 == 0)
@@ -331,17 +334,17 @@ template <int J, int STAMP> __device__ __forceinline__ void history_block(Regs &
         else
                 asm volatile(ASLAM_T16_H1_O : "+{v[48:63]}"(R.o), ASLAM_T16_P_OUT : ASLAM_T16_Q_IN, ASLAM_T16_COMMON(a_nxt, RN, 3) : ASLAM_T16_SCRATCH);
         pp.template stamp<STAMP>(2);
-        pp.template end<(J == 0) ? 16 : 12>();
+        pp.template end<(J == 0) ? 16 + NST : (J == 1) ? 12 + NST : 12>(); // (NST: the stores of the closing block one / two blocks back)
         pp.template stamp<STAMP>(3);
 }
 
-template <int J, int STAMP> __device__ __forceinline__ void chain(Regs &R, int k, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
+template <int J, int STAMP, int NST> __device__ __forceinline__ void chain(Regs &R, int k, Pipe &pp, Seq &seq, int a_h0, int a_h1, int tid)
 {
         if (J < k)
         {
-                history_block<J, STAMP>(R, pp, seq, a_h0, a_h1, tid);
+                history_block<J, STAMP, NST>(R, pp, seq, a_h0, a_h1, tid);
                 if constexpr (J + 1 < LARGE_NB_MAX - 1)
-                        chain<J + 1, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
+                        chain<J + 1, STAMP, NST>(R, k, pp, seq, a_h0, a_h1, tid);
         }
 }
 
@@ -436,6 +439,7 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
         if constexpr (STAMP)
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pp.tlast)::"memory");
         const int klast = CHOL ? nbk : nbk - 1;
+        constexpr int NST = CHOL ? 10 : 4; // vector-memory stores of a closing block per wave (V: 4; the planes of L: 6)
 #pragma unroll 1
         for (int k = 0; k <= klast; ++k)
         {
@@ -460,11 +464,14 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                         R.run[i] = R.e[i] = R.o[i] = 0.f;
-                chain<0, STAMP>(R, k, pp, seq, a_h0, a_h1, tid);
+                chain<0, STAMP, NST>(R, k, pp, seq, a_h0, a_h1, tid);
                 // ---- the closing block of column k: C = rows - history (running sum + the sums of the last history block, which no later block has
                 // added), X = C Linv_k^T (Linv is lower triangular in tiles: output tile t needs c tiles <= t).  Set P holds the first-half rows of
-                // Linv_k.  This column's slice of the rows was issued one block column ago: at most the six pieces of the last history block are younger.
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                // Linv_k.  This column's slice of the rows was issued one block column ago.
+                // (k >= 1: issued at the top of closing block k - 1 -- its DMA pieces, its stores and the pieces of >= 1 history block are younger;
+                // k = 0 and the Cholesky's diagonal column: everything was waited for at the (re)start)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + NST) : "memory");
+                pp.template stamp<STAMP>(9);
                 f4 g0[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -472,6 +479,7 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (!(CHOL && k == nbk))
                         g_issue(CHOL ? k + 1 : min(k + 1, nbk - 1)); // the next slice (ahead of this block's pieces of L: Pipe::end counts on that order)
+                pp.template stamp<STAMP>(10);
                 asm volatile("s_nop 15" : "+v"(R.e), "+v"(R.o)); // MFMA results -> VALU
                 {
                         const bool last_even = (k & 1) != 0; // history block k - 1
@@ -479,7 +487,7 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                         for (int t = 0; t < 4; ++t)
                         {
                                 const f4 last = last_even ? tile4(R.e, t) : tile4(R.o, t);
-                                const f4 ct = k > 0 ? g0[t] - (tile4(R.run, t) + last) : g0[t];
+                                const f4 ct = k > 0 ? g0[t] - (tile4(R.run, t) + last) : g0[t]; // (the select keeps hipcc from hoisting the sums: without it the Cholesky parks registers in the strip's AGPRs)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
                                         R.run[4 * t + r] = ct[r]; // C takes the place of the running sum
@@ -532,6 +540,7 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                                 __builtin_amdgcn_raw_buffer_store_b128((u4v){l0[0], l0[1], l1[0], l1[1]}, rows.rq, (int)rows.vq, so + 2 * (int)rows.qplane, 0);
                         }
                 }
+                pp.template stamp<STAMP>(11);
                 switch (k)
                 {
 #define ASLAM_T16_KEEP(K)                                                                                              \
@@ -565,7 +574,12 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                         split8(s8, R.Pbh, R.Pbm, R.Pbl);
                 }
                 pp.template stamp<STAMP>(8);
-                pp.template end<16>();
+                if constexpr (STAMP)
+                {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NST) : "memory");
+                        pp.template stamp<STAMP>(12);
+                }
+                pp.template end<16 + NST>();
                 pp.template stamp<STAMP>(4);
         }
         (void)nb_rows;
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
         asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
         if constexpr (STAMP)
                 if (tid == 0 && blockIdx.x == 0)
-                        for (int i = 0; i < 9; ++i)
+                        for (int i = 0; i < 13; ++i)
                                 lv.Y[i] = (double)pp.ph[i];
 }
 
@@ -633,7 +647,6 @@ __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<f
         const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
         float *Sb = lv.S + (size_t)b * NP * NP;
         float *Linv = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
-        unsigned short *Liq = pl.Liq(b, NP);
         asm volatile("" ::: "a0", "a255"); // the strip
         Rows rows;
         rows.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Sb), 0, NP * NP * 4, 0x00020000);
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<f
                         }
                 }
                 ok = chol64::factor_and_invert<true>(tiles, tid) && ok;
-                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, Liq + (size_t)I * 3 * LB * LB);
+                chol64::store_block(tiles, Sb + ((size_t)LB * I) * NP + (size_t)LB * I, NP, Linv + (size_t)I * LB * LB, tid, pl.block(b, NP, I, I));
                 // the next block row reads the planes back through the block pipeline
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -718,10 +731,9 @@ __global__ __launch_bounds__(256) void large_split_planes(DevView d, LargeView<f
         else
         {
                 const float *Li = lv.Linv + (size_t)b * LARGE_NB_MAX * LB * LB;
-                unsigned short *Liq = pl.Liq(b, NP);
                 for (int k = 0; k < nb; ++k)
                         for (int r = r0; r < LB; r += 16)
-                                put(Li + (size_t)k * LB * LB + r * LB + c, Liq + (size_t)k * 3 * LB * LB + r * LB + perm_pos(c), (size_t)LB * LB);
+                                put(Li + (size_t)k * LB * LB + r * LB + c, pl.block(b, NP, k, k) + (size_t)r * NP + perm_pos(c), (size_t)NP * NP);
         }
 }
 } // namespace aslam

@@ -101,7 +101,7 @@ def region(src, dst, acc, first, prev, half_next, strip=True, tiles=4, rows=4, d
     for q, piece in enumerate(dma):
         g = 2 + (q * (n - 4)) // max(1, len(dma))
         dma_at[g] = f"s_add_u32 m0, %[ldsw], {(piece >> 1) * 8192 + (piece & 1) * 4096}"
-        dma_at[g + 1] = f"buffer_load_dwordx4 %[voff], %[rsrc], %[so{q}] offen lds"
+        dma_at[g + 1] = f"buffer_load_dwordx4 %[vo{q}], %[rsrc], %[so] offen lds"
     for i, m in enumerate(mf):
         lines.append(m)
         if i in dma_at:
@@ -137,6 +137,7 @@ def main():
         "H1_E_NOVALU": region("Q", "P", "E", False, None, 0, diag="novalu", dma=(3, 4, 5)),
         "H1_E_NODS": region("Q", "P", "E", False, None, 0, diag="nods", dma=(3, 4, 5)),
         "H1_E_BARE": region("Q", "P", "E", False, None, 0, diag="novalu nods"),
+        "H1_E_NODMA": region("Q", "P", "E", False, None, 0),
     }
     out = ["// GENERATED by tools/gen_trsm16_regions.py -- do not edit (the register map and the interleave are described there)"]
     for name, lines in variants.items():

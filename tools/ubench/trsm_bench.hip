@@ -221,13 +221,14 @@ int main(int argc, char **argv)
                         auto stamps = [&](const char *name, auto kern) {
                                 hipLaunchKernelGGL(kern, dim3(8 * ((15 + 7) / 8) * NB), dim3(256), 0, 0, d, lw, pl, 15, dskip);
                                 CK(hipDeviceSynchronize());
-                                double y[9];
+                                double y[13];
                                 CK(hipMemcpy(y, dY, sizeof(y), hipMemcpyDeviceToHost));
                                 std::printf("  trsm_bf16 %-34s workgroup 0 of 255, shader cycles per block: first-half region %.0f, mid %.0f, second-half region %.0f, barrier %.0f; closing block %.0f; total %.0f\n",
-                                            name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, (y[4] + y[5] + y[6] + y[7] + y[8]) / 17, y[0] + y[1] + y[2] + y[3] + y[4] + y[5] + y[6] + y[7] + y[8]);
-                                std::printf("      closing block: C + split %.0f, first half %.0f, second half %.0f, stores + strip %.0f, wait + barrier %.0f\n", y[5] / 17, y[6] / 17, y[7] / 17, y[8] / 17, y[4] / 17);
+                                            name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, (y[4] + y[5] + y[6] + y[7] + y[8] + y[9] + y[10] + y[11] + y[12]) / 17, y[0] + y[1] + y[2] + y[3] + y[4] + y[5] + y[6] + y[7] + y[8] + y[9] + y[10] + y[11] + y[12]);
+                                std::printf("      closing block: wait for the slice %.0f, its LDS reads + issue of the next %.0f, C + split %.0f, first half %.0f, second half %.0f, stores %.0f, strip write %.0f, vmcnt wait %.0f, barrier %.0f\n", y[9] / 17, y[10] / 17, y[5] / 17, y[6] / 17, y[7] / 17, y[11] / 17, y[8] / 17, y[12] / 17, y[4] / 17);
                         };
                         stamps("product", large_trsm_bf16<LARGE_NB_MAX, 1>);
+                        stamps("second half: no DMA pieces", large_trsm_bf16<LARGE_NB_MAX, 5>);
                         stamps("second half: no VALU", large_trsm_bf16<LARGE_NB_MAX, 2>);
                         stamps("second half: no LDS reads", large_trsm_bf16<LARGE_NB_MAX, 3>);
                         stamps("second half: MFMAs only", large_trsm_bf16<LARGE_NB_MAX, 4>);
