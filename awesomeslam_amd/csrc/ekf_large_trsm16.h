@@ -259,6 +259,20 @@ struct Pipe
         {
                 static_assert(LATER >= 12 && LATER <= 63, "vmcnt count");
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LATER) : "memory");
+                rotate();
+        }
+        /// the same with the count chosen at run time (wave-uniform): 16 in the block that follows a closing block (its four stores), else 12
+        __device__ __forceinline__ void end_dyn(bool after_closing)
+        {
+                if (after_closing)
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else
+                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                rotate();
+        }
+        __device__ __forceinline__ void rotate()
+        {
                 unsigned short *t = b0;
                 b0 = b1;
                 b1 = b2;

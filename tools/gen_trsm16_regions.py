@@ -117,6 +117,41 @@ def region(src, dst, acc, first, prev, half_next, strip=True, tiles=4, rows=4, d
     return lines
 
 
+def rregion(src, dst, dma):
+    """Right-looking history half (large_trsm_bf16r): the 24 MFMAs of one half block accumulate STRAIGHT INTO THE STRIP -- tile t of block column K
+    = a[r0 + 4 t .. + 3], r0 = 16 K a compile-time operand -- with the pieces of the (negated) solved column as B operand; behind them only the
+    twelve operand-row reads of the next half and three DMA pieces: no VALU instruction at all."""
+    a_src, b_src, a_dst = SETS[src]["A"], SETS[src]["B"], SETS[dst]["A"]
+    mf = []
+    for s, (p, piece) in enumerate(PRODUCTS):
+        for t in range(4):
+            d = f"a[%c[r0]+{4 * t}:%c[r0]+{4 * t + 3}]"
+            a = f"v[{a_src + 16 * p + 4 * t}:{a_src + 16 * p + 4 * t + 3}]"
+            b = f"v[{b_src + BOFF[piece]}:{b_src + BOFF[piece] + 3}]"
+            mf.append(f"v_mfma_f32_16x16x32_bf16 {d}, {a}, {b}, {d}")
+    ds = []
+    for p in range(3):
+        for t in range(4):
+            off = (16 * t * PLD + p * PLANE) * 2
+            ds.append(f"ds_read_b128 v[{a_dst + 16 * p + 4 * t}:{a_dst + 16 * p + 4 * t + 3}], %[lds] offset:{off}")
+    n = len(mf)
+    dma_at = {}
+    for q, piece in enumerate(dma):
+        g = 2 + (q * (n - 4)) // max(1, len(dma))
+        dma_at[g] = f"s_add_u32 m0, %[ldsw], {(piece >> 1) * 8192 + (piece & 1) * 4096}"
+        dma_at[g + 1] = f"buffer_load_dwordx4 %[vo{q}], %[rsrc], %[so] offen lds"
+    lines = []
+    for i, m in enumerate(mf):
+        lines.append(m)
+        if i in dma_at:
+            lines.append(dma_at[i])
+        if ds:
+            lines.append(ds.pop(0))
+    lines.append("s_waitcnt lgkmcnt(0)")
+    lines.append("s_nop 1")
+    return lines
+
+
 def cstring(lines):
     return "\n".join(f'        "{ln}\\n\\t"' for ln in lines[:-1]) + f'\n        "{lines[-1]}"'
 
@@ -138,6 +173,10 @@ def main():
         "H1_E_NODS": region("Q", "P", "E", False, None, 0, diag="nods", dma=(3, 4, 5)),
         "H1_E_BARE": region("Q", "P", "E", False, None, 0, diag="novalu nods"),
         "H1_E_NODMA": region("Q", "P", "E", False, None, 0),
+        # right-looking sweep (large_trsm_bf16r): history halves into the strip; the closing block's second half without a strip operand
+        "R0": rregion("P", "Q", (0, 1, 2)),
+        "R1": rregion("Q", "P", (3, 4, 5)),
+        "C1R": region("Q", "P", "E", False, None, 0, strip=False, tiles=2, dma=(3, 4, 5)),
     }
     out = ["// GENERATED by tools/gen_trsm16_regions.py -- do not edit (the register map and the interleave are described there)"]
     for name, lines in variants.items():

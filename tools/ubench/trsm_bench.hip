@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "ekf_large.h"
+#include "trsm16_right_looking.h"
 
 using namespace aslam;
 
@@ -179,7 +180,11 @@ int main(int argc, char **argv)
                 CK(hipMemset(pl.base, 0, sizeof(unsigned short) * t16::Planes::per_filter(NP) * B));
                 const float msp = time_ms([&]() { hipLaunchKernelGGL(large_split_planes<0>, dim3(NB + 1, B), dim3(256), 0, 0, d, lv, pl, dskip); }, 3);
                 reset_G();
-                hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, B, dskip);
+                const bool rl = std::getenv("RIGHT") != nullptr; // RIGHT=1: the right-looking experiment (trsm16_right_looking.h) in this section instead of the library's kernel
+                auto k16 = rl ? large_trsm_bf16r<LARGE_NB_MAX, 0> : large_trsm_bf16<LARGE_NB_MAX, 0>;
+                auto k16s = rl ? large_trsm_bf16r<LARGE_NB_MAX, 1> : large_trsm_bf16<LARGE_NB_MAX, 1>;
+                std::printf("bf16 sweep: %s\n", rl ? "right-looking (large_trsm_bf16r)" : "left-looking (large_trsm_bf16)");
+                hipLaunchKernelGGL(k16, dim3(8 * ((B + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, B, dskip);
                 CK(hipDeviceSynchronize());
                 std::vector<float> V2(M);
                 CK(hipMemcpy(V2.data(), dG + M * (B - 1), sizeof(float) * M, hipMemcpyDeviceToHost));
@@ -210,7 +215,7 @@ int main(int argc, char **argv)
                 {
                         if (bb > B)
                                 break;
-                        const float m0 = time_ms([&]() { hipLaunchKernelGGL((large_trsm_bf16<LARGE_NB_MAX>), dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, bb, dskip); }, 5);
+                        const float m0 = time_ms([&]() { hipLaunchKernelGGL(k16, dim3(8 * ((bb + 7) / 8) * NB), dim3(256), 0, 0, d, lv, pl, bb, dskip); }, 5);
                         std::printf("  trsm_bf16 %3d filters: %7.3f ms\n", bb, m0);
                 }
                 {
@@ -227,11 +232,14 @@ int main(int argc, char **argv)
                                             name, y[0] / 136, y[1] / 136, y[2] / 136, y[3] / 136, (y[4] + y[5] + y[6] + y[7] + y[8] + y[9] + y[10] + y[11] + y[12]) / 17, y[0] + y[1] + y[2] + y[3] + y[4] + y[5] + y[6] + y[7] + y[8] + y[9] + y[10] + y[11] + y[12]);
                                 std::printf("      closing block: wait for the slice %.0f, its LDS reads + issue of the next %.0f, C + split %.0f, first half %.0f, second half %.0f, stores %.0f, strip write %.0f, vmcnt wait %.0f, barrier %.0f\n", y[9] / 17, y[10] / 17, y[5] / 17, y[6] / 17, y[7] / 17, y[11] / 17, y[8] / 17, y[12] / 17, y[4] / 17);
                         };
-                        stamps("product", large_trsm_bf16<LARGE_NB_MAX, 1>);
+                        stamps("product", k16s);
+                        if (!rl)
+                        {
                         stamps("second half: no DMA pieces", large_trsm_bf16<LARGE_NB_MAX, 5>);
                         stamps("second half: no VALU", large_trsm_bf16<LARGE_NB_MAX, 2>);
                         stamps("second half: no LDS reads", large_trsm_bf16<LARGE_NB_MAX, 3>);
                         stamps("second half: MFMAs only", large_trsm_bf16<LARGE_NB_MAX, 4>);
+                        }
                 }
         }
         if (only && std::string(only) == "trsm16")
