@@ -555,31 +555,11 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
                         }
                 }
                 pp.template stamp<STAMP>(11);
-                switch (k)
+                if (k < 16) // (the last block column is never a history block)
                 {
-#define ASLAM_T16_KEEP(K)                                                                                              \
-        case K:                                                                                                        \
-                strip_write16<K>(x);                                                                                   \
-                break;
-                        ASLAM_T16_KEEP(0)
-                        ASLAM_T16_KEEP(1)
-                        ASLAM_T16_KEEP(2)
-                        ASLAM_T16_KEEP(3)
-                        ASLAM_T16_KEEP(4)
-                        ASLAM_T16_KEEP(5)
-                        ASLAM_T16_KEEP(6)
-                        ASLAM_T16_KEEP(7)
-                        ASLAM_T16_KEEP(8)
-                        ASLAM_T16_KEEP(9)
-                        ASLAM_T16_KEEP(10)
-                        ASLAM_T16_KEEP(11)
-                        ASLAM_T16_KEEP(12)
-                        ASLAM_T16_KEEP(13)
-                        ASLAM_T16_KEEP(14)
-                        ASLAM_T16_KEEP(15)
-                default:
-                        break; // the last block column is never a history block
-#undef ASLAM_T16_KEEP
+                        // x -> strip registers a[16 k ..]: a computed jump (tools/gen_trsm16_regions.py); x is still in the accumulator registers
+                        const int ks = __builtin_amdgcn_readfirstlane(k);
+                        asm volatile(ASLAM_T16_STRIP_WRITE_DYN : : [k] "s"(ks), "{v[32:47]}"(R.e) : "s96", "s97", "s98", "scc");
                 }
                 if (k == 0)
                 {

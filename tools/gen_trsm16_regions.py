@@ -152,6 +152,19 @@ def rregion(src, dst, dma):
     return lines
 
 
+def strip_write_dyn():
+    """x (v[32:47], the closing block's accumulators) -> strip registers a[16 k .. 16 k + 15] for a RUN-TIME block column k (0 .. 15, in a scalar
+    register): a computed jump into a table of sixteen 136-byte entries (sixteen 8-byte v_accvgpr_write + s_branch + s_nop).  hipcc compiles the
+    equivalent switch into a tree of compares and branches that costs ~ 600 cycles per closing block (trsm_bench phase stamps)."""
+    lines = ["s_getpc_b64 s[96:97]", ".Lt16_pc_%=:", "s_mul_i32 s98, %[k], 136", "s_add_u32 s96, s96, s98", "s_addc_u32 s97, s97, 0",
+             "s_add_u32 s96, s96, .Lt16_tab_%=-.Lt16_pc_%=", "s_addc_u32 s97, s97, 0", "s_setpc_b64 s[96:97]", ".Lt16_tab_%=:"]
+    for k in range(16):
+        lines += [f"v_accvgpr_write_b32 a{16 * k + i}, v{ACC['E'] + i}" for i in range(16)]
+        lines += ["s_branch .Lt16_end_%=", "s_nop 0"]
+    lines += [".Lt16_end_%=:", "s_nop 3"]
+    return lines
+
+
 def cstring(lines):
     return "\n".join(f'        "{ln}\\n\\t"' for ln in lines[:-1]) + f'\n        "{lines[-1]}"'
 
@@ -177,6 +190,7 @@ def main():
         "R0": rregion("P", "Q", (0, 1, 2)),
         "R1": rregion("Q", "P", (3, 4, 5)),
         "C1R": region("Q", "P", "E", False, None, 0, strip=False, tiles=2, dma=(3, 4, 5)),
+        "STRIP_WRITE_DYN": strip_write_dyn(),
     }
     out = ["// GENERATED by tools/gen_trsm16_regions.py -- do not edit (the register map and the interleave are described there)"]
     for name, lines in variants.items():
