@@ -23,7 +23,14 @@ def chol_mode(dtype, monkeypatch):
     """binary32 mode factors S either as 33 multi-workgroup launches (the default below 32 filters) or in one launch with a filter per
     workgroup (large_chol_resident, the default from 32 filters on: what bench.py runs); "f32-resident" forces the latter on these
     small batches through the environment variable the context reads when it is created"""
-    monkeypatch.setenv("ASLAM_CHOL_RESIDENT", "1" if dtype.endswith("-resident") else "0")
+    monkeypatch.setenv("ASLAM_CHOL_RESIDENT", "1" if "-resident" in dtype else "0")
+    # "-pipeN": which of the resident kernels run on the bf16 matrix pipe (ASLAM_BF16_PIPE; default 3 = large_chol_bf16 + large_trsm_bf16):
+    # 0 = the fp32-MFMA pair (large_chol_resident + large_trsm_pipe), 1 / 2 = the mixed pairs (the planes written by large_chol_resident /
+    # the binary32 factor of large_chol_bf16 solved by large_trsm_pipe)
+    if "-pipe" in dtype:
+        monkeypatch.setenv("ASLAM_BF16_PIPE", dtype.split("-pipe")[1])
+    else:
+        monkeypatch.delenv("ASLAM_BF16_PIPE", raising=False)
     return dtype.split("-")[0]
 
 
@@ -88,7 +95,7 @@ def test_indefinite_innovation_covariance_is_flagged(dtype, built, monkeypatch):
     assert core.status(1) & ST_NOT_PD
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident", "f32-resident-pipe0", "f32-resident-pipe1", "f32-resident-pipe2"])
 @pytest.mark.parametrize("L,T,kw", [(80, 150, dict(seed=61)), (100, 80, dict(seed=62, sensor_every=2, dt_mode="random"))])
 def test_replay_parity(L, T, kw, dtype, built, monkeypatch):
     import torch
@@ -216,6 +223,36 @@ def test_config4_512_landmarks(built, monkeypatch):
         errs = rel_err(poses.cpu().numpy()[0], po), rel_err(X, Xo), cov_err(P, Po)
         print(f"config 4 (n=1027) {'f32' if dtype == F32 else 'f64'}{' resident' if resident == '1' else ''}: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
         assert max(errs) < tol
+
+
+def test_identical_trajectories_stay_bit_identical_with_every_cu_busy(built):
+    """256 copies of ONE 512-landmark trajectory through the benchmarked chain (fp32 products, four stream groups, the bf16-pipe Cholesky and
+    TRSM): every filter runs the same instructions on the same numbers, so poses and covariances must agree BIT FOR BIT -- whatever each
+    workgroup's neighbours and the memory system are doing.  Round 3's first integration of large_chol_bf16 / large_trsm_bf16 read LDS-DMA data
+    one block early: right in every test that left the chip mostly idle, wrong by 1e-4 at this batch (tools/ubench/trsm_bench.hip carries
+    the same check on the kernels alone)."""
+    import torch
+    from awesomeslam_amd.core import Core, F32
+
+    L, T, B = 512, 48, 256
+    tr = tg.make_traces(L, T, B=1, seed=73).select([0] * B)
+    core = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=F32)
+    core.set_trace(tr)
+    poses = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    dims = torch.zeros((B, T), dtype=torch.int32, device="cuda")
+    core.replay(0, T, poses.data_ptr(), dims.data_ptr())
+    torch.cuda.synchronize()
+    assert "bf16" in core.kernel_info()["name"] and core.launch_info()["stream_groups"] == 4
+    dims = dims.cpu().numpy()
+    assert dims[0, -1] == tg.full_dim(L) and (dims == dims[0]).all()
+    poses = poses.cpu().numpy()
+    differing = [b for b in range(B) if not np.array_equal(poses[b], poses[0])]
+    assert not differing, f"{len(differing)} of {B} identical trajectories left the pose stream of filter 0 (first: {differing[:5]})"
+    X0, Z0, P0 = core.state(0)
+    for b in (1, 63, 64, 127, 128, 200, 255):
+        X, Z, P = core.state(b)
+        assert core.status(b) == 0 and np.array_equal(X, X0) and np.array_equal(Z, Z0) and np.array_equal(P, P0), f"filter {b} differs from filter 0"
+    core.close()
 
 
 def test_host_mirror_on_the_large_path(built):
