@@ -16,8 +16,12 @@
 //   * Accumulation: a block sums its 48 MFMAs in accumulators that start at zero and the VALU adds the block's sums to the column's running sum
 //     -- an MFMA truncates small addends it adds to a large accumulator (tools/ubench/mfma_rounding.hip); running sums over a whole block
 //     column were the source of the round-2 bias.
-// Everything except the strip accesses is plain HIP (builtins): with the B operand in VGPRs the MFMAs no longer name AGPRs, and the
-// compiler schedules MFMAs, conversions and LDS reads (sched_group_barrier pins the interleave).
+//   * The inner loop is hand-scheduled: a half block is ONE asm statement (tools/gen_trsm16_regions.py -> ekf_large_trsm16_regions.inc) whose
+//     operands are bound to fixed register tuples; the blocks of L arrive by LDS-DMA into five buffers, their pieces issued inside those
+//     statements and counted with s_waitcnt vmcnt (Pipe).  A wave is alone on its SIMD and issues in order, so every VALU instruction of the split
+//     adds to the MFMAs' time: DESIGN.md section 6 and profiles/r03_experiments.md section 3 have the cycle budget of a block.
+// The translation unit that includes this header for its kernels (aslam_large16.hip) is compiled with -mllvm -amdgpu-mfma-vgpr-form: with the AGPRs
+// reserved for the strip hipcc would otherwise pick the AGPR form of every MFMA builtin.
 #pragma once
 
 namespace aslam
@@ -100,19 +104,6 @@ template <int K> __device__ __forceinline__ void strip_write16(const f4 (&x)[4])
                        "n"(16 * K + 14), "n"(16 * K + 15));
 }
 
-__device__ __forceinline__ f4 mm(const u4v &a, const u4v &b, const f4 &c)
-{
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
-}
-
-/// the operands of one half block (32 of its 64 columns): A = the rows of the staged block (four row tiles x three planes, one 16-byte LDS read
-/// each), B = the three pieces of this lane's eight contraction slots
-struct Ops
-{
-        u4v A[4][3];
-        u4v bh, bm, bl;
-};
-
 /// this lane's operand rows of half h: row 16 t + li, chunk (4 h + lg) ^ (li & 7), planes 0 .. 2.  a_row = li * PLD (elements)
 template <int T0 = 0> __device__ __forceinline__ void load_frags(u4v (&A)[4][3], const unsigned short *buf, int a_h)
 {
@@ -121,43 +112,6 @@ template <int T0 = 0> __device__ __forceinline__ void load_frags(u4v (&A)[4][3],
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                         A[t][p] = *reinterpret_cast<const u4v *>(buf + a_h + 16 * t * PLD + p * PLANE);
-}
-
-/// acc[t] (+)= block rows 16 t .. 16 t + 15 (half h) x operand, t = T0 .. 3; FIRST: acc[t] starts here (accumulator operand 0).  The six
-/// products of a tile are a dependent chain; consecutive MFMAs belong to different row tiles.
-template <bool FIRST, int T0 = 0> __device__ __forceinline__ void mfmas(f4 (&acc)[4], const Ops &o)
-{
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][0], o.bl, FIRST ? (f4){0.f, 0.f, 0.f, 0.f} : acc[t]); // small terms first
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][1], o.bm, acc[t]);
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][2], o.bh, acc[t]);
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][0], o.bm, acc[t]);
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][1], o.bh, acc[t]);
-#pragma unroll
-        for (int t = T0; t < 4; ++t)
-                acc[t] = mm(o.A[t][0], o.bh, acc[t]);
-}
-
-/// scheduling hints for a region of NM MFMAs that carries the next half's conversion and LDS reads: 1 MFMA, 2 VALU, and an LDS read every other gap
-template <int NM> __device__ __forceinline__ void interleave()
-{
-#pragma unroll
-        for (int i = 0; i < NM; ++i)
-        {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
-                if (i % 2 == 0)
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
-        }
 }
 
 /// a wave-uniform pointer the compiler computed with vector instructions (64-bit multiplies) -> scalar registers
@@ -384,12 +338,6 @@ __device__ __forceinline__ void load_planes(u16v &A0, u16v &A1, u16v &A2, const 
                         A0[4 * t + r] = A[t][0][r], A1[4 * t + r] = A[t][1][r], A2[4 * t + r] = A[t][2][r];
 }
 
-/// c (four tiles, accumulator layout: c[t][r] = column 16 t + 4 lg + r of row li) -> the operand of half h
-__device__ __forceinline__ void split_c(const f4 (&c)[4], int h, u4v &bh, u4v &bm, u4v &bl)
-{
-        const float x[8] = {c[2 * h][0], c[2 * h][1], c[2 * h][2], c[2 * h][3], c[2 * h + 1][0], c[2 * h + 1][1], c[2 * h + 1][2], c[2 * h + 1][3]};
-        split8(x, bh, bm, bl);
-}
 } // namespace t16
 
 namespace t16
