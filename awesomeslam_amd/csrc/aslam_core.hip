@@ -76,6 +76,7 @@ struct aslam_ctx
         // chip that way, as 33 multi-workgroup launches (diagonal block + panel per block column) for few filters.
         // ASLAM_CHOL_RESIDENT=0/1 forces one form.
         int chol_resident = -1;
+        int right_step = 1;   // binary32 mode below the resident batch: the right-looking one-launch-per-block-column chain (large_right_step); ASLAM_RIGHT_STEP=0: the left-looking chain of rounds 1 - 2 (potrf + panel launches, large_trsm_pipe)
         int bf16_pipe = 3;    // binary32 mode, resident Cholesky: Cholesky and TRSM on the bf16 matrix pipe (large_chol_bf16 + large_trsm_bf16, ekf_large_trsm16.h); ASLAM_BF16_PIPE=0: the fp32-MFMA kernels
         int syrk_running = 0; // diagnostic (ASLAM_SYRK_RUNNING=1): round 2's accumulation order in large_syrk_bf16x3 (profiles/r03_experiments.md)
         static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
@@ -165,6 +166,8 @@ template <typename T> int init_P_large(aslam_ctx *c, LargeView<T> &lv)
         HIP_TRY(hipMemset(lv.P, 0, sizeof(double) * B * NP * NP));
         HIP_TRY(hipMemset(lv.G, 0, sizeof(T) * B * NP * NP));
         HIP_TRY(hipMemset(lv.S, 0, sizeof(T) * B * NP * NP));
+        if (lv.Vw)
+                HIP_TRY(hipMemset(lv.Vw, 0, sizeof(T) * B * NP * NP));
         std::vector<double> blk(3 * NP, 0.0);
         for (int i = 0; i < 3; ++i)
                 blk[(size_t)i * NP + i] = (double)KP_ROBOT_POSE;
@@ -309,8 +312,12 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 g.v.Hc += b * (np / 2) * 4;
                 g.v.Linv += b * LARGE_NB_MAX * LB * LB;
                 if constexpr (sizeof(T) == 4)
+                {
                         if (g.v.Lpl)
                                 g.v.Lpl += b * LPlanes::per_filter((int)np);
+                        if (g.v.Vw)
+                                g.v.Vw += b * np * np;
+                }
                 g.v.Y += b * np;
                 g.skip += b;
                 return g;
@@ -322,15 +329,27 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 hipLaunchKernelGGL(large_build_GS<T>, dim3(1 + (NP / 2 + GS_ROW_PAIRS - 1) / GS_ROW_PAIRS, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                 const int ntile = (NP + 127) / 128;
                 const dim3 syrk_grid(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8));
+                LargeView<T> vv = g.v; // what the consumers of V read
                 if constexpr (sizeof(T) == 4)
                 {
                         // binary32: Cholesky of S alone (17 x {diagonal block, panel of S}), then V = G L^-T with the solved columns
                         // resident in registers (one launch), then P -= V V^T into the fp64 covariance
+                        const bool right = !resident && c->right_step && g.v.Vw != nullptr;
                         const bool pipe16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 1), chol16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 2);
                         if (chol16)
                                 launch_chol_bf16(g.dv, g.v, gb, g.skip, g.st);
                         else if (resident)
                                 hipLaunchKernelGGL(large_chol_resident<LARGE_NB_MAX>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                        else if (right)
+                        {
+                                hipLaunchKernelGGL(large_potrf_inv_tiles<T>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, 0, g.skip);
+                                for (int k = 0; k < NB; ++k)
+                                {
+                                        const int M = NB - k - 1;
+                                        hipLaunchKernelGGL(large_right_step<0>, dim3(M * (M + 1) / 2 + NB * M + NB, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, g.skip);
+                                }
+                                vv.G = g.v.Vw; // V is there, row n = q included
+                        }
                         else
                                 for (int k = 0; k < NB; ++k)
                                 {
@@ -338,14 +357,16 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                         if (k + 1 < NB)
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
-                        if (pipe16)
+                        if (right)
+                                ;
+                        else if (pipe16)
                                 launch_trsm_bf16(g.dv, g.v, gb, g.skip, g.st);
                         else
                                 hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         if (c->syrk_running)
-                                hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                                hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
                         else
-                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
+                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
                 }
                 else
                 {
@@ -357,7 +378,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
                 if constexpr (sizeof(T) == 4)
-                        hipLaunchKernelGGL((large_x_update_rows<MODE>), dim3((NP + 4 * XU_ROWS - 1) / (4 * XU_ROWS), gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps,
+                        hipLaunchKernelGGL((large_x_update_rows<MODE>), dim3((NP + 4 * XU_ROWS - 1) / (4 * XU_ROWS), gb), dim3(256), 0, g.st, g.dv, vv, s, nsteps,
                                            g.poses, g.dims, g.skip);
                 else
                         hipLaunchKernelGGL((large_x_update<T, MODE, false>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses, g.dims,
@@ -365,7 +386,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         };
         const int NG = c->large_groups;
         c->last_resident = (sizeof(T) == 4 && resident) ? 1 : 0;
-        c->last_launches = sizeof(T) == 4 ? (resident ? 6 : 4 + 2 * NB) : 4 + 2 * NB;
+        c->last_launches = sizeof(T) == 4 ? (resident ? 6 : (c->right_step && c->lv32.Vw ? 5 + NB : 4 + 2 * NB)) : 4 + 2 * NB;
         c->last_groups = 1;
         if (MODE == MODE_STEP && sa.traj >= 0)
         {
@@ -531,6 +552,8 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         c->chol_resident = std::atoi(e) != 0;
                 if (const char *e = std::getenv("ASLAM_SYRK_RUNNING"))
                         c->syrk_running = std::atoi(e) != 0;
+                if (const char *e = std::getenv("ASLAM_RIGHT_STEP"))
+                        c->right_step = std::atoi(e) != 0;
                 if (const char *e = std::getenv("ASLAM_BF16_PIPE"))
                         c->bf16_pipe = std::atoi(e) & 3; // bit 0: the TRSM, bit 1: the Cholesky (diagnostics: 1 = large_chol_resident writes the planes, 2 = large_trsm_pipe solves)
                 for (hipStream_t &q : c->aux)
@@ -553,6 +576,9 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         A_(dev_alloc(c, &c->lv32.Linv, B * LARGE_NB_MAX * LB * LB, c->owned));
                         if (c->bf16_pipe)
                                 A_(dev_alloc(c, &c->lv32.Lpl, B * LPlanes::per_filter((int)NP), c->owned));
+                        const bool may_be_resident = c->chol_resident >= 0 ? c->chol_resident != 0 : cfg->batch >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
+                        if (c->right_step && !may_be_resident)
+                                A_(dev_alloc(c, &c->lv32.Vw, B * NP * NP, c->owned));
                 }
                 else
                 {
@@ -1232,6 +1258,8 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
                 else if (c->cfg.dtype == ASLAM_F32 && resident)
                         std::snprintf(buf, sizeof(buf), "large_chol_resident + large_trsm_pipe<%d> + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)",
                                       (int)LARGE_NB_MAX, c->large_groups);
+                else if (c->cfg.dtype == ASLAM_F32 && c->right_step && c->lv32.Vw)
+                        std::snprintf(buf, sizeof(buf), "large_right_step + large_syrk_bf16x3 (%d-launch chain per callback: one right-looking launch per block column)", 5 + c->NP / LB);
                 else if (c->cfg.dtype == ASLAM_F32)
                         std::snprintf(buf, sizeof(buf), "large_trsm_pipe<%d> + large_syrk_bf16x3 (%d-launch chain per callback: multi-workgroup Cholesky)",
                                       (int)LARGE_NB_MAX, 4 + 2 * (c->NP / LB));

@@ -46,6 +46,7 @@ template <typename T> struct LargeView
         double *Hc; // [B][NP/2][4] h00 h01 h10 h11 per landmark
         double *Y;  // [B][NP]
         T *Linv;    // [B][LARGE_NB_MAX][LB][LB]  inverses of the diagonal blocks of L
+        T *Vw;      // [B][NP][NP]  binary32 mode, few-filter chain (large_right_step): V is written HERE, not over G (every block of G is read by many workgroups of a launch); else nullptr
         unsigned short *Lpl; // binary32 mode with the bf16-pipe TRSM: LPlanes::base (bf16 planes of L and of the inverses, written by large_chol_resident), else nullptr
 };
 

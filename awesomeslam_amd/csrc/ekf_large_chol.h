@@ -243,6 +243,144 @@ template <typename T> __global__ __launch_bounds__(256) void large_potrf_inv_til
                 atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
 }
 
+/// Few filters per launch (batch < 32: batch 1 is configs[4]), binary32: ONE launch per block column k does everything that depends on the
+/// factor of diagonal block k -- RIGHT-looking, so that no launch is deeper than three 64x64x64 products and a 64x64 factorisation, and a
+/// filter's work spreads over as many workgroups as it has tiles (the chip is empty at this batch: redundant work is free, launches and serial
+/// depth are what cost).  With Linv_k = L(k,k)^-1 (from the previous launch) a workgroup takes one 64x64 tile:
+///   S tile (i, j), k < j <= i:   X_i = S(i,k) Linv_k^T,  X_j = S(j,k) Linv_k^T  (both recomputed by every workgroup that needs them: L(i,k) is
+///                                never stored -- nothing reads it afterwards),  S(i,j) -= X_i X_j^T.
+///                                Tile (k+1, k+1) is then the next diagonal block, complete: the same workgroup factors and inverts it
+///                                (chol64::factor_and_invert, as large_potrf_inv_tiles) -- the 17 diagonal launches of the left-looking chain are gone;
+///   G tile (g, j), j > k:        G(g,j) -= (G(g,k) Linv_k^T) X_j^T  -- the rows of G are solved by the same launches (no TRSM launch);
+///   V panel g:                   V(g,k) = G(g,k) Linv_k^T -> lv.Vw: final.  (Not over G(g,k): the G tiles of this launch read it.)
+/// Measured at batch 1, n = 1027 (profiles/r03_batch1_breakdown.txt): the left-looking chain spent 836 us per callback in 33 launches of the
+/// Cholesky and 162 in the TRSM.  grid (tiles(k), 1, B) with tiles(k) = M (M + 1) / 2 + NB M + NB, M = NB - k - 1; 256 threads.
+template <int UNUSED = 0> // (a template: the header is included by both translation units of the library)
+__global__ __launch_bounds__(256) void large_right_step(DevView d, LargeView<float> lv, int k, const int *skipped)
+{
+        typedef Mfma<float> MM;
+        constexpr int LD = LB + 8; // 18 sixteen-byte slots per row: conflict-free ds_read_b128 operand reads (as large_update_panel)
+        constexpr int PROD_BYTES = 3 * LB * LD * (int)sizeof(float), TILE_BYTES = chol64::TILES * TSZ * (int)sizeof(double);
+        __shared__ __attribute__((aligned(16))) unsigned char raw[PROD_BYTES > TILE_BYTES ? PROD_BYTES : TILE_BYTES];
+        float(*As)[LD] = reinterpret_cast<float(*)[LD]>(raw);
+        float(*Bs)[LD] = As + LB;
+        float(*Is)[LD] = Bs + LB;
+        double *tiles = reinterpret_cast<double *>(raw); // the diagonal factorisation, once the products are done with the operands
+        const int b = blockIdx.z;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        if (k >= nb)
+                return;
+        const int m = nb - k - 1, nS = m * (m + 1) / 2, nG = nb * m;
+        const int idx = blockIdx.x;
+        int type, ri, cj = k;
+        if (idx < nS)
+        {
+                int ii = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+                while ((ii + 1) * (ii + 2) / 2 <= idx)
+                        ++ii;
+                while (ii * (ii + 1) / 2 > idx)
+                        --ii;
+                type = 0, ri = k + 1 + ii, cj = k + 1 + (idx - ii * (ii + 1) / 2);
+        }
+        else if (idx < nS + nG)
+                type = 1, ri = (idx - nS) / m, cj = k + 1 + (idx - nS) % m;
+        else if (idx < nS + nG + nb)
+                type = 2, ri = idx - nS - nG;
+        else
+                return;
+        float *S = lv.S + (size_t)b * NP * NP, *G = lv.G + (size_t)b * NP * NP;
+        const float *Ablk = (type == 0 ? S : G) + (size_t)(LB * ri) * NP + LB * k;
+        const float *Bblk = S + (size_t)(LB * cj) * NP + LB * k;
+        const float *Li = lv.Linv + ((size_t)b * LARGE_NB_MAX + k) * LB * LB;
+        const bool same = (type == 0 && ri == cj), two = (type != 2 && !same);
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+                const int e = tid + 256 * q, r = e >> 4, c4 = (e & 15) * 4;
+                *reinterpret_cast<f4 *>(&As[r][c4]) = *reinterpret_cast<const f4 *>(Ablk + (size_t)r * NP + c4);
+                *reinterpret_cast<f4 *>(&Is[r][c4]) = *reinterpret_cast<const f4 *>(Li + r * LB + c4);
+                if (two)
+                        *reinterpret_cast<f4 *>(&Bs[r][c4]) = *reinterpret_cast<const f4 *>(Bblk + (size_t)r * NP + c4);
+        }
+        __syncthreads();
+        // acc[v] = rows 16 wave .. + 15 of A times rows 16 v .. + 15 of B, transposed: sum_t A(r, t) B(c, t); one 16-byte LDS read per operand row
+        // feeds four MFMA steps (lane (li, lg) holds t = 16 c + 4 lg + r for step r: a permuted walk over the contraction index, the same for both)
+        auto prod = [&](const float(*A)[LD], const float(*Bm)[LD], f4(&acc)[4]) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        acc[v] = MM::zero();
+#pragma unroll
+                for (int c = 0; c < LB / 16; ++c)
+                {
+                        const f4 av = *reinterpret_cast<const f4 *>(&A[16 * wave + li][16 * c + 4 * lg]);
+                        f4 bv[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                                bv[v] = *reinterpret_cast<const f4 *>(&Bm[16 * v + li][16 * c + 4 * lg]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                        acc[v] = MM::mma(av[r], bv[v][r], acc[v]);
+                }
+        };
+        f4 xa[4], xb[4];
+        prod(As, Is, xa);
+        if (type == 2)
+        {
+                float *V = lv.Vw + (size_t)b * NP * NP + (size_t)(LB * ri + 16 * wave) * NP + LB * k;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                                V[(size_t)MM::row(lane, r) * NP + 16 * v + li] = xa[v][r];
+                return;
+        }
+        if (two)
+                prod(Bs, Is, xb);
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                        As[16 * wave + MM::row(lane, r)][16 * v + li] = xa[v][r];
+                        if (two)
+                                Bs[16 * wave + MM::row(lane, r)][16 * v + li] = xb[v][r];
+                }
+        __syncthreads();
+        f4 c[4];
+        prod(As, two ? Bs : As, c);
+        float *C = (type == 0 ? S : G) + (size_t)(LB * ri + 16 * wave) * NP + LB * cj;
+        if (same && ri == k + 1)
+        {
+                // the next diagonal block is complete with this update: factor it here
+                __syncthreads(); // (the tiles alias the operands)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                        if (v <= wave)
+                        {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        chol64::Lt(tiles, wave, v)[MM::row(lane, r) * TLD + li] = (double)(C[(size_t)MM::row(lane, r) * NP + 16 * v + li] - c[v][r]);
+                        }
+                const bool ok = chol64::factor_and_invert<true>(tiles, tid);
+                chol64::store_block(tiles, S + (size_t)(LB * ri) * NP + LB * ri, NP, lv.Linv + ((size_t)b * LARGE_NB_MAX + ri) * LB * LB, tid);
+                if (!ok && tid == 0)
+                        atomicOr(&d.status[b], 4u); // ASLAM_ST_NOT_PD
+                return;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                        C[(size_t)MM::row(lane, r) * NP + 16 * v + li] -= c[v][r];
+}
+
 /// grid (B), 256 threads: the Cholesky factor of S (lower block triangle, in place) and the inverses of its diagonal blocks (lv.Linv)
 /// for filter blockIdx.x.  Status bit 4 (ASLAM_ST_NOT_PD) on a non-positive pivot.
 template <int NBMAX, int STAMP = 0>

@@ -20,13 +20,18 @@ F32_DRIFT_TOL = 1e-6  # 500 ... 2000 callbacks at n = 1027 against the fp64 path
 
 
 def chol_mode(dtype, monkeypatch):
-    """binary32 mode factors S either as 33 multi-workgroup launches (the default below 32 filters) or in one launch with a filter per
-    workgroup (large_chol_resident, the default from 32 filters on: what bench.py runs); "f32-resident" forces the latter on these
-    small batches through the environment variable the context reads when it is created"""
+    """binary32 mode factors S either with one right-looking launch per block column (large_right_step, the default below 32 filters) or in
+    one launch with a filter per workgroup (the resident kernels, the default from 32 filters on: what bench.py runs); "f32-resident"
+    forces the latter on these small batches through the environment variable the context reads when it is created"""
     monkeypatch.setenv("ASLAM_CHOL_RESIDENT", "1" if "-resident" in dtype else "0")
     # "-pipeN": which of the resident kernels run on the bf16 matrix pipe (ASLAM_BF16_PIPE; default 3 = large_chol_bf16 + large_trsm_bf16):
     # 0 = the fp32-MFMA pair (large_chol_resident + large_trsm_pipe), 1 / 2 = the mixed pairs (the planes written by large_chol_resident /
     # the binary32 factor of large_chol_bf16 solved by large_trsm_pipe)
+    # "-left": the left-looking few-filter chain of rounds 1 - 2 (33 Cholesky launches + large_trsm_pipe) instead of large_right_step
+    if "-left" in dtype:
+        monkeypatch.setenv("ASLAM_RIGHT_STEP", "0")
+    else:
+        monkeypatch.delenv("ASLAM_RIGHT_STEP", raising=False)
     if "-pipe" in dtype:
         monkeypatch.setenv("ASLAM_BF16_PIPE", dtype.split("-pipe")[1])
     else:
@@ -95,7 +100,7 @@ def test_indefinite_innovation_covariance_is_flagged(dtype, built, monkeypatch):
     assert core.status(1) & ST_NOT_PD
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident", "f32-resident-pipe0", "f32-resident-pipe1", "f32-resident-pipe2"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-left", "f32-resident", "f32-resident-pipe0", "f32-resident-pipe1", "f32-resident-pipe2"])
 @pytest.mark.parametrize("L,T,kw", [(80, 150, dict(seed=61)), (100, 80, dict(seed=62, sensor_every=2, dt_mode="random"))])
 def test_replay_parity(L, T, kw, dtype, built, monkeypatch):
     import torch
