@@ -2,7 +2,7 @@
 #   gpurun --timeout 900 -- 'bash tools/manual/profile_round.sh r3p'
 # Outputs under gpurun_out/<tag>/ (copy what is to be kept into profiles/):
 #   stats4/          rocprofv3 --kernel-trace --stats of the default launch shape (4 stream groups)
-#   trace1.csv       kernel trace with ONE stream group (every launch covers all 256 filters: single-stream kernel durations)
+#   kernel_stats_1group.csv, one_stream_breakdown.txt   kernel trace + stats with ONE stream group (every launch covers all 256 filters: single-stream kernel durations)
 #   sq/              --pmc SQ_* pass (one stream group): MFMA utilisation per kernel (tools/pmc_summary.py)
 #   fetch/, write/   --pmc FETCH_SIZE / WRITE_SIZE passes (separate, as the guide prescribes)
 # rocprofv3 gets the program itself after `--` (python3 bench.py ...): no env / bash -c hop (the box refuses an exec from a process that holds the GPU).
@@ -12,7 +12,8 @@ mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 BENCH="python3 bench.py --no-sub --no-legs --cpu-sample 0 --steps 5 --warmup 2"   # (the synthetic trace depends on its length: with --steps 3 one landmark of trajectory 224 is not promoted in the prologue -- in the CPU oracle too -- and bench.py refuses to time that)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -o s -- $BENCH > $OUT/stats4_bench.json 2> $OUT/stats4.err
 export ASLAM_LARGE_GROUPS=1
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace1 -o t -- $BENCH > $OUT/trace1_bench.json 2> $OUT/trace1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o t -- $BENCH > $OUT/trace1_bench.json 2> $OUT/trace1.err
+find $OUT/trace1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_1group.csv \;
 python3 - $OUT <<"PY"
 import csv, collections, sys, glob
 out = sys.argv[1]
