@@ -332,8 +332,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 LargeView<T> vv = g.v; // what the consumers of V read
                 if constexpr (sizeof(T) == 4)
                 {
-                        // binary32: Cholesky of S alone (17 x {diagonal block, panel of S}), then V = G L^-T with the solved columns
-                        // resident in registers (one launch), then P -= V V^T into the fp64 covariance
+                        // binary32: from 32 filters on the resident kernels (one launch each: Cholesky of S with a filter per workgroup, then V = G L^-T with
+                        // the solved columns in registers); below that one right-looking launch per block column that factors S and solves the rows of G
+                        // together (large_right_step; ASLAM_RIGHT_STEP=0: rounds 1 - 2's 17 x {diagonal block, panel of S} + large_trsm_pipe); then
+                        // P -= V V^T into the fp64 covariance
                         const bool right = !resident && c->right_step && g.v.Vw != nullptr;
                         const bool pipe16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 1), chol16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 2);
                         if (chol16)
@@ -357,11 +359,9 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                                         if (k + 1 < NB)
                                                 hipLaunchKernelGGL(large_update_panel<T>, dim3((NB - k) / 2, 1, gb), dim3(256), 0, g.st, g.dv, g.v, k, 1, g.skip);
                                 }
-                        if (right)
-                                ;
-                        else if (pipe16)
+                        if (pipe16)
                                 launch_trsm_bf16(g.dv, g.v, gb, g.skip, g.st);
-                        else
+                        else if (!right) // (large_right_step has solved the rows of G on its way)
                                 hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         if (c->syrk_running)
                                 hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
