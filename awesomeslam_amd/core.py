@@ -27,7 +27,7 @@ CORE_SYMBOLS = (
     "aslam_get_layout", "aslam_kernel_info", "aslam_get_launch_info",
 )
 NODE_SYMBOLS = (
-    "aslam_node_create", "aslam_node_destroy", "aslam_node_error", "aslam_node_sensor", "aslam_node_odom",
+    "aslam_node_create", "aslam_node_create_at", "aslam_node_destroy", "aslam_node_error", "aslam_node_sensor", "aslam_node_odom",
     "aslam_node_odom_now", "aslam_node_dim", "aslam_node_get", "aslam_node_wait", "aslam_node_core",
     "aslam_host_narrow_odom",
 )
@@ -53,55 +53,53 @@ class TraceView(ctypes.Structure):
                 ("obs", ctypes.c_void_p)]
 
 
-def build(force=False, ukf=True):
-    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU).  The Makefile scans the device assembly of the very compilation
-    that produces libaslam_core.so (tools/check_spill_exec.py, tools/check_agpr_strip.py) and moves the library into place only when
-    both guards are clean, so a library that failed one is never left where core_lib() would load it.  Writes csrc/build_info.json
-    (rebuilt or reused, compiler, time) for __graft_entry__.smoke() to print."""
-    import json
-    import time
+_BUILT_HERE = False  # set by build() when THIS process's make run (re)compiled libaslam_core.so
 
-    tools = os.path.join(_CSRC, "..", "..", "tools")
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
-    srcs += [os.path.join(_CSRC, "host", f) for f in os.listdir(os.path.join(_CSRC, "host"))]
-    srcs += [os.path.join(_CSRC, "Makefile"), os.path.join(_CSRC, "..", "..", "include", "aslam_core.h"),
-             os.path.join(tools, "check_spill_exec.py"), os.path.join(tools, "check_agpr_strip.py"), os.path.join(tools, "gen_trsm16_regions.py")]
-    stale = force or not (os.path.exists(_CORE) and os.path.exists(_NODE)) or any(
-        os.path.getmtime(s) > min(os.path.getmtime(_CORE), os.path.getmtime(_NODE)) for s in srcs)
-    info_path = os.path.join(_CSRC, "build_info.json")
-    if stale:
-        have_ukf = ukf and os.path.exists(os.path.join(_CSRC, "ukf_small.h"))
-        try:
-            subprocess.check_call(["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "all"])
-        except subprocess.CalledProcessError:
-            # a failed guard leaves no library behind (the Makefile builds under a temporary name); make sure of it even for a failure
-            # in a later step, so that the next build() cannot mistake an unchecked library for a fresh one
-            for f in (_CORE, _NODE):
-                if os.path.exists(f) and any(os.path.getmtime(s) > os.path.getmtime(f) for s in srcs):
-                    os.remove(f)
-            raise
-        try:
-            ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
-            ver = next((ln.strip() for ln in ver.splitlines() if "HIP version" in ln), ver.strip().splitlines()[0] if ver.strip() else "?")
-        except OSError:
-            ver = "?"
-        info = {"built": time.strftime("%Y-%m-%d %H:%M:%S"), "host": os.uname().nodename, "hipcc": ver, "arch": "gfx950", "ukf": bool(have_ukf),
-                "guards": "check_spill_exec + check_agpr_strip clean on the assembly of this compilation"}
-        with open(info_path, "w") as f:
-            json.dump(info, f)
+
+def _sha256(path):
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def build(force=False, ukf=True):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU): `make all`, which decides itself what is stale.  The Makefile scans
+    the device assembly of the very compilation that produces libaslam_core.so (tools/check_spill_exec.py, check_agpr_strip.py,
+    check_vmcnt_protocol.py), moves the library into place only when all guards are clean -- a library that failed one is never left where
+    core_lib() would load it; GUARDS=0 installs under another name -- and THEN writes csrc/build_info.json (sha256 of the library, hash of
+    the sources, guards, compiler, time) from the same rule, so the record always describes the file under the loader's name."""
+    global _BUILT_HERE
+    have_ukf = ukf and os.path.exists(os.path.join(_CSRC, "ukf_small.h"))
+    before = _sha256(_CORE) if os.path.exists(_CORE) else None
+    cmd = ["make", "-s", "-C", _CSRC, f"UKF={1 if have_ukf else 0}", "GUARDS=1"] + (["-B"] if force else []) + ["all"]
+    subprocess.check_call(cmd)
+    _BUILT_HERE = _BUILT_HERE or before != _sha256(_CORE)
     return _CORE, _NODE
 
 
 def build_info():
-    """What build() recorded for the libraries in csrc/, plus whether THIS process found them up to date ("reused") or compiled them."""
+    """The record the Makefile wrote for csrc/libaslam_core.so, CHECKED against the file that is there now: "matches_library" is True only
+    when the sha256 in the record is the sha256 of the library core_lib() loads (False: the record describes some other binary -- the library
+    was replaced behind the Makefile's back; None: no record).  "reused_here": this process did not compile it (it came with the snapshot)."""
     import json
 
     p = os.path.join(_CSRC, "build_info.json")
     try:
         info = json.load(open(p))
     except (OSError, ValueError):
-        info = {"built": "unknown (no build_info.json: the libraries were not produced by core.build())"}
-    info["reused_here"] = info.get("host") != os.uname().nodename
+        info = {"built": "unknown (no build_info.json: the library was not installed by csrc/Makefile)"}
+    info.pop("sources", None)
+    if "sha256" in info and os.path.exists(_CORE):
+        info["matches_library"] = info["sha256"] == _sha256(_CORE)
+        if not info["matches_library"]:
+            info["built"] = "unknown (build_info.json does not describe the libaslam_core.so that is loaded)"
+    else:
+        info["matches_library"] = None
+    info["reused_here"] = not _BUILT_HERE
     return info
 
 
@@ -158,6 +156,8 @@ def node_lib():
         pd, pf, pu = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_float, ctypes.c_uint32))
         L.aslam_node_create.restype = vp
         L.aslam_node_create.argtypes = [ci, ci, ci]
+        L.aslam_node_create_at.restype = vp
+        L.aslam_node_create_at.argtypes = [ci, ci, ci, ctypes.c_double]
         L.aslam_node_destroy.argtypes = [vp]
         L.aslam_node_error.restype = ctypes.c_char_p
         L.aslam_node_sensor.argtypes = [vp, ci, pd, pd]
@@ -463,8 +463,9 @@ class Core:
 class Node:
     """aslam::EKFSlam / aslam::UKFSlam host mirror (C++), driving the per-callback seam of the core."""
 
-    def __init__(self, filter="ekf", max_landmark_count=30, device=0):
-        h = node_lib().aslam_node_create(FILTERS[filter], int(max_landmark_count), int(device))
+    def __init__(self, filter="ekf", max_landmark_count=30, device=0, now_init=0.0):
+        """`now_init`: the clock reading (seconds) at construction -- initialize()'s last_time = ros::Time::now().toSec() (ekf.cpp:54)"""
+        h = node_lib().aslam_node_create_at(FILTERS[filter], int(max_landmark_count), int(device), float(now_init))
         if not h:
             raise AslamError(node_lib().aslam_node_error().decode())
         self._h = ctypes.c_void_p(h)

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
         Pipe pp;
         Regs R;
         f4 c[4];
-        asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
+        asm volatile("; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4" ::: "memory"); // (tools/check_vmcnt_protocol.py: what Pipe's counts assume)
         sweep16<STAMP, false>(c, R, pp, lds, gl[wv], pl, b, nb, nb, NP, rows, tid);
         asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
         if constexpr (STAMP)
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<f
                 rows.out = Sb + (size_t)(LB * I + 16 * wave + li) * NP + 4 * lg;
                 rows.vq = (unsigned)(((LB * I + 16 * wave + li) * NP + 8 * lg) * 2);
                 f4 c[4];
-                asm volatile("; ASLAM_STRIP_LIVE_BEGIN" ::: "memory");
+                asm volatile("; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4 buffer_store_dwordx4=6" ::: "memory"); // (tools/check_vmcnt_protocol.py)
                 sweep16<0, true>(c, R, pp, lds, gl[wv], pl, b, I, nb, NP, rows, tid);
                 asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
                 // every DMA piece still in flight targets the buffers the tiles are about to take

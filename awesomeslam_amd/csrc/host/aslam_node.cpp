@@ -62,9 +62,10 @@ float quat2euler(float w, float x, float y, float z)
         return std::atan2(2 * (w * z + x * y), 1 - 2 * (z * z + y * y));
 }
 
-FilterNode::FilterNode(int filter_, int max_landmark_count, int device)
+FilterNode::FilterNode(int filter_, int max_landmark_count, int device, double now_init)
     : filter(filter_), MAX_LANDMARK_COUNT(max_landmark_count), ctx(nullptr), N(3), init_z(true), init_x(true),
-      last_time(0.0f), growth_refused(false), param_X(3, 0.0), param_Z(3, 0.0), a00(1.0), a10(0.0)
+      last_time((float)now_init), // ekf.cpp:54: last_time = ros::Time::now().toSec(), a float member (ekf.h:98)
+      growth_refused(false), param_X(3, 0.0), param_Z(3, 0.0), a00(1.0), a10(0.0)
 {
         aslam_config cfg = {};
         cfg.filter = filter;
@@ -263,10 +264,15 @@ extern "C" {
 
 aslam_node *aslam_node_create(int filter, int max_landmark_count, int device)
 {
+        return aslam_node_create_at(filter, max_landmark_count, device, 0.0);
+}
+
+aslam_node *aslam_node_create_at(int filter, int max_landmark_count, int device, double now_init)
+{
         try
         {
                 aslam_node *n = new aslam_node();
-                n->impl = new aslam::FilterNode(filter, max_landmark_count, device);
+                n->impl = new aslam::FilterNode(filter, max_landmark_count, device, now_init);
                 return n;
         }
         catch (const std::exception &e)

@@ -48,7 +48,8 @@ float quat2euler(float w, float x, float y, float z);
 class FilterNode
 {
       public:
-        FilterNode(int filter, int max_landmark_count, int device);
+        /// `now_init` stands for the ros::Time::now().toSec() of initialize() (ekf.cpp:54 / ukf.cpp:54): it seeds the binary32 last_time
+        FilterNode(int filter, int max_landmark_count, int device, double now_init = 0.0);
         virtual ~FilterNode();
         FilterNode(const FilterNode &) = delete;
         FilterNode &operator=(const FilterNode &) = delete;
@@ -120,7 +121,7 @@ class FilterNode
 class EKFSlam : public FilterNode
 {
       public:
-        explicit EKFSlam(int max_landmark_count = 30, int device = 0) : FilterNode(ASLAM_EKF, max_landmark_count, device)
+        explicit EKFSlam(int max_landmark_count = 30, int device = 0, double now_init = 0.0) : FilterNode(ASLAM_EKF, max_landmark_count, device, now_init)
         {
         }
 };
@@ -128,7 +129,7 @@ class EKFSlam : public FilterNode
 class UKFSlam : public FilterNode
 {
       public:
-        explicit UKFSlam(int max_landmark_count = 30, int device = 0) : FilterNode(ASLAM_UKF, max_landmark_count, device)
+        explicit UKFSlam(int max_landmark_count = 30, int device = 0, double now_init = 0.0) : FilterNode(ASLAM_UKF, max_landmark_count, device, now_init)
         {
         }
 };
@@ -139,6 +140,9 @@ extern "C" {
 typedef struct aslam_node aslam_node;
 /* filter: ASLAM_EKF | ASLAM_UKF.  NULL on failure (aslam_node_error()). */
 aslam_node *aslam_node_create(int filter, int max_landmark_count, int device);
+/* the same with the construction time of the node (seconds): initialize() stores ros::Time::now().toSec() in the binary32 last_time
+ * (ekf.cpp:54), which the first delta_time of aslam_node_odom_now() is measured from.  aslam_node_create = ..._at(..., 0.0). */
+aslam_node *aslam_node_create_at(int filter, int max_landmark_count, int device, double now_init);
 void aslam_node_destroy(aslam_node *n);
 const char *aslam_node_error(void);
 int aslam_node_sensor(aslam_node *n, int count, const double *x, const double *y);

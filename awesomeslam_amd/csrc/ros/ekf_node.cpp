@@ -1,61 +1,7 @@
-// ros/ekf_node.cpp -- `rosrun awesome_slam ekf`: the reference's node surface (awesome_slam/src/ekf/ekf.cpp:39-46,313-326:
-// node name aslam_ekf, /odom and /out/landmarks/sensor with queue size 1, out/landmarks/kalman, 1 Hz spin loop) on top of
-// the host mirror aslam::EKFSlam, whose covariance and slam() live on the MI355X behind include/aslam_core.h.
-//
-// Compile-gated: built only where catkin/roscpp and awesome_slam_msgs exist (ros/CMakeLists.txt).  The build image of
-// this repository has no ROS, so this file has never been compiled here; the classes it wraps are tested through the
-// aslam_node_* C shim (tests/test_gpu_ekf.py::test_per_callback_seam_host_mirror).
-#include <awesome_slam_msgs/Landmarks.h>
-#include <nav_msgs/Odometry.h>
-#include <ros/ros.h>
-
-#include <iostream>
-
-#include "../host/aslam_node.h"
-
-namespace
-{
-aslam::EKFSlam *filter = nullptr;
-ros::Publisher pub_landmark;
-
-void cbOdom(const nav_msgs::Odometry::ConstPtr &msg)
-{
-        const aslam::Odometry o{msg->pose.pose.position.x,    msg->pose.pose.position.y,    msg->pose.pose.orientation.w,
-                                msg->pose.pose.orientation.x, msg->pose.pose.orientation.y, msg->pose.pose.orientation.z,
-                                msg->twist.twist.linear.x,    msg->twist.twist.angular.z};
-        if (!filter->cbOdom(o, ros::Time::now().toSec()))
-                return; // no sensor message yet (ekf.cpp:76-77)
-        const aslam::Landmarks l = filter->landmarks(); // convertToLandmarkMsg, common.h:93-108
-        awesome_slam_msgs::Landmarks out;
-        out.x = l.x;
-        out.y = l.y;
-        pub_landmark.publish(out);
-}
-
-void cbSensorLandmark(const awesome_slam_msgs::Landmarks::ConstPtr &msg)
-{
-        filter->cbSensorLandmark(aslam::Landmarks{msg->x, msg->y});
-}
-} // namespace
+// ros/ekf_node.cpp -- `rosrun awesome_slam ekf` (awesome_slam/src/ekf/ekf.cpp:313-326): node aslam_ekf, subscriber queues of size 1.
+#include "node_main.h"
 
 int main(int argc, char **argv)
 {
-        ros::init(argc, argv, "aslam_ekf");
-        ros::Time::init();
-        ros::NodeHandle nh;
-        int max_landmark_count = 30; // config.h:45; a private parameter here instead of a recompile
-        ros::param::param("~max_landmark_count", max_landmark_count, 30);
-        aslam::EKFSlam node(max_landmark_count);
-        filter = &node;
-        ros::Subscriber sub_odom = nh.subscribe("/odom", 1, cbOdom);
-        ros::Subscriber sub_sensor_landmark = nh.subscribe("/out/landmarks/sensor", 1, cbSensorLandmark);
-        pub_landmark = nh.advertise<awesome_slam_msgs::Landmarks>("out/landmarks/kalman", 1);
-        ros::Rate rate(1); // FREQ, config.h:42
-        std::cerr << "[EKF] Node started!\n";
-        while (ros::ok())
-        {
-                ros::spinOnce();
-                rate.sleep();
-        }
-        return 0;
+        return aslam_ros::node_main<aslam::EKFSlam>(argc, argv, "aslam_ekf", 1, "[EKF] Node started!\n");
 }

@@ -10,8 +10,11 @@ Input: the CSV text `rostopic echo -b run.bag -p /odom` and `rostopic echo -b ru
   narrows range/bearing to binary32 (`structures.h:85-101`);
 * odometry callbacks before the first Landmarks message return early without touching anything (`ekf.cpp:76-77`): they
   are recorded (the trace replays that branch too), with `dt` as the node would compute it once it gets past the gate:
-  `delta_time = float(min(now - last_time, 1.0))` with `last_time` only advanced by callbacks past the gate (`ekf.cpp:79-81`),
-  `last_time = 0` initially.
+  `float delta_time = std::min(now - last_time, 1.0)` with `last_time` a BINARY32 member (`ekf.h:98`) that only callbacks past the gate
+  advance (`ekf.cpp:79-81`) and that `initialize()` sets to `ros::Time::now().toSec()` when the node is constructed (`ekf.cpp:54`).  The
+  narrowing matters: with epoch-sized stamps (1.7e9 s) a float has 128 s granularity, so the reference's `delta_time` is `now` minus a
+  multiple of 128 s -- anything in (-64, 1.0] --, and with sim-time stamps of a few hundred seconds it still moves `dt` by up to 1.5e-5.
+  This module reproduces that arithmetic exactly (np.float32 `last_time`).
 
 A spin without a new odometry message runs no cbOdom and produces no callback in the trace (a Landmarks message that arrived
 in it is kept for the next callback, as the node keeps `sensor_landmark`).
@@ -63,9 +66,17 @@ def parse_landmarks_csv(text):
     return np.array(t, np.int64), msgs
 
 
-def to_trace(odom_csv, landmarks_csv, freq_hz=1.0, t_start_ns=None):
+def _to_sec(ns):
+    """ros::Time::toSec(): (double)sec + 1e-9 * (double)nsec -- NOT ns * 1e-9, which rounds differently at epoch-sized stamps"""
+    ns = int(ns)
+    return float(ns // 10**9) + 1e-9 * float(ns % 10**9)
+
+
+def to_trace(odom_csv, landmarks_csv, freq_hz=1.0, t_start_ns=None, t_init_ns=None):
     """Replay the node's spin loop over the two recorded topics.  `t_start_ns` is the time of the spin before the first one
-    (the phase of the node's 1 Hz clock against the recording is not in the recording; default: the first message's stamp)."""
+    (the phase of the node's 1 Hz clock against the recording is not in the recording; default: the first message's stamp);
+    `t_init_ns` is the time the node was constructed -- `initialize()` stores it in the binary32 `last_time` (`ekf.cpp:54`) -- and
+    defaults to `t_start_ns`."""
     to, mo = parse_odom_csv(odom_csv)
     tl, ml = parse_landmarks_csv(landmarks_csv)
     if len(to) == 0:
@@ -78,7 +89,7 @@ def to_trace(odom_csv, landmarks_csv, freq_hz=1.0, t_start_ns=None):
     io_, il = 0, 0
     pending = None        # a Landmarks message delivered in a spin without odometry
     gate_open = False     # init_z == false
-    last_time = 0.0
+    last_time = np.float32(_to_sec(t0 if t_init_ns is None else t_init_ns))  # ekf.cpp:54, narrowed by the float member (ekf.h:98)
     spin = t0
     while spin - period < last_stamp:
         spin += period    # messages with stamp <= spin are in the queues when spinOnce() runs
@@ -94,12 +105,12 @@ def to_trace(odom_csv, landmarks_csv, freq_hz=1.0, t_start_ns=None):
             pending = lm
         if od is None:
             continue
-        now = spin * 1e-9
+        now = _to_sec(spin)
         if pending is not None:
             gate_open = True
-        dt = np.float32(min(now - last_time, 1.0))
+        dt = np.float32(min(now - float(last_time), 1.0))  # ekf.cpp:80: double - (double)float, min in double, narrowed to float
         if gate_open:
-            last_time = now
+            last_time = np.float32(now)                   # ekf.cpp:81
         odom.append(od)
         dts.append(dt)
         if pending is not None:

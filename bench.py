@@ -382,17 +382,22 @@ def roofline(workload, B, C, kernel_s, kernel_name=""):
     peak = PEAK_F32_TFLOPS if large else PEAK_F64_TFLOPS
     achieved = algorithmic_flops(kind, n) * B * C / kernel_s / 1e12
     executed = executed_flops(workload, n) * B * C / kernel_s / 1e12
-    traffic = None
+    # PMC traffic is a stored measurement (profiles/pmc_traffic.json, separate --pmc passes): it is reported only when the entry was taken on
+    # the SAME kernel chain this run launched (the entry's "kernel" must equal aslam_kernel_info's name); otherwise traffic is null
+    traffic, traffic_note = None, None
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tj):
         try:
             ent = json.load(open(tj)).get(workload, {})
-            traffic = ent.get("hbm_bytes_per_launch")
-            if traffic is not None and ent.get("trajectories") and ent.get("callbacks_per_launch"):
-                # the PMC passes are per launch of the shape they were taken at: scale to this launch's callbacks x trajectories
-                traffic = traffic * (B * C) / (ent["trajectories"] * ent["callbacks_per_launch"])
-        except Exception:
-            traffic = None
+            if ent.get("kernel") != kernel_name:
+                traffic_note = f"profiles/pmc_traffic.json[{workload}] was measured on kernel {ent.get('kernel')!r}, this run launched {kernel_name!r}: not reported"
+            else:
+                traffic = ent.get("hbm_bytes_per_launch")
+                if traffic is not None and ent.get("trajectories") and ent.get("callbacks_per_launch"):
+                    # the PMC passes are per launch of the shape they were taken at: scale to this launch's callbacks x trajectories
+                    traffic = traffic * (B * C) / (ent["trajectories"] * ent["callbacks_per_launch"])
+        except Exception as e:  # noqa: BLE001
+            traffic, traffic_note = None, f"profiles/pmc_traffic.json unreadable: {e}"
     mixed = None
     if large:
         # ADVICE / VERDICT round 2: `frac` divides fp32-equivalent flops by the fp32 MFMA peak although part of them runs on the (faster) bf16
@@ -405,7 +410,7 @@ def roofline(workload, B, C, kernel_s, kernel_name=""):
                  "note": "time of the 2.33 n^3 algorithmic flops at the peaks of the pipes they run on (fp32 MFMA 157.3 T; bf16x3 = dense bf16 "
                          "peak / 6 = 419 T fp32-equivalent, 308 T measured by tools/ubench/mfma_bf16x3.hip) / measured launch time"}
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "executed_frac": executed / peak, "mixed_pipe_frac": None if mixed is None else mixed["frac"], "mixed_pipe": mixed, "traffic": traffic,
+            "executed_frac": executed / peak, "mixed_pipe_frac": None if mixed is None else mixed["frac"], "mixed_pipe": mixed, "traffic": traffic, "traffic_note": traffic_note,
             # the other roofline north_star asks for: PMC bytes at the L2's memory side per launch / launch time
             "hbm": None if traffic is None else {"achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                                  "frac": traffic / kernel_s / 1e9 / PEAK_HBM_GBPS},
@@ -440,6 +445,16 @@ def main():
                     help="skip the batch-1 latency and PCIe-inclusive legs (profiling runs: the timed steps are then the last launches)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and os.environ.get("ASLAM_DIST_BACKEND") != "gloo":
+        # one process per GPU over RCCL: more ranks than devices cannot work (two ranks on one device deadlock in the communicator set-up);
+        # ASLAM_DIST_BACKEND=gloo is the rehearsal in which ranks share devices.  torch.cuda.device_count() does not initialise the GPU.
+        import torch
+
+        if torch.cuda.device_count() == 0:
+            raise SystemExit("bench.py needs a GPU: the filter core has no CPU fallback")
+        if args.gpus > torch.cuda.device_count():
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s); one rank per GPU over RCCL needs "
+                             f"{args.gpus}.  (ASLAM_DIST_BACKEND=gloo rehearses the multi-process path with ranks sharing devices.)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 

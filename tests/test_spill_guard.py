@@ -43,7 +43,7 @@ def test_product_assembly_is_clean():
     csrc = os.path.join(ROOT, "awesomeslam_amd", "csrc")
     r = subprocess.run(["make", "-s", "-C", csrc, "check-spills"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
-    assert b"check_spill_exec: clean" in r.stdout and b"check_agpr_strip: clean" in r.stdout
+    assert b"check_spill_exec: clean" in r.stdout and b"check_agpr_strip: clean" in r.stdout and b"check_vmcnt_protocol: clean" in r.stdout
 
 
 STRIP = """
@@ -70,6 +70,37 @@ _ZN5aslam19large_chol_residentILi17ELi0EEEv:  ; @_ZN5aslam19large_chol_residentI
 	;;#ASMEND
 	v_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[6:7], 0
 	s_endpgm
+_ZN5aslam15large_chol_bf16ILi17EEEv:  ; @_ZN5aslam15large_chol_bf16ILi17EEEv
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=1 buffer_store_dwordx4=2
+	;;#ASMEND
+.LBB2_1:
+	global_store_dwordx4 v[0:1], v[2:5], off
+	buffer_store_dwordx4 v[2:5], v0, s[0:3], 0 offen
+	buffer_store_dwordx4 v[2:5], v0, s[0:3], 0 offen
+	s_cbranch_scc1 .LBB2_1
+%s
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_END
+	;;#ASMEND
+.LBB2_2:
+	s_endpgm
+_ZN5aslam15large_trsm_bf16ILi17ELi0EEEv:  ; @_ZN5aslam15large_trsm_bf16ILi17ELi0EEEv
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4
+	;;#ASMEND
+	global_store_dwordx4 v[0:1], v[2:5], off
+	global_store_dwordx4 v[0:1], v[2:5], off
+	global_store_dwordx4 v[0:1], v[2:5], off
+	global_store_dwordx4 v[0:1], v[2:5], off
+	;;#ASMSTART
+	buffer_load_dwordx4 v0, s[0:3], 0 offen lds
+	s_waitcnt vmcnt(12)
+	;;#ASMEND
+	;;#ASMSTART
+	; ASLAM_STRIP_LIVE_END
+	;;#ASMEND
+	s_endpgm
 """
 
 
@@ -81,6 +112,34 @@ def test_agpr_strip_detector(tmp_path):
     for name, filler, want in (("ok.s", "\tv_add_f32_e32 v1, v2, v3", 0), ("spill.s", "\tv_accvgpr_write_b32 a3, v5 ;  Reload Reuse", 1),
                                ("mfma.s", "\tv_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[6:7], 0", 1)):
         p = tmp_path / name
-        p.write_text(STRIP % filler)
+        p.write_text(STRIP % (filler, ""))
         f = g.scan(str(p))
         assert len(f) == want, (name, f)
+    # a branch that leaves a live range (a cold block laid out behind the END marker) makes the linear-order reading unsound
+    p = tmp_path / "cold.s"
+    p.write_text(STRIP % ("\tv_add_f32_e32 v1, v2, v3", "\ts_cbranch_scc0 .LBB2_2"))
+    f = g.scan(str(p))
+    assert len(f) == 1 and "out of" in f[0][2], f
+    # a strip kernel without markers: the guard would be vacuous
+    p = tmp_path / "nomarkers.s"
+    p.write_text((STRIP % ("\tv_add_f32_e32 v1, v2, v3", "")).replace("; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4", "; nothing").replace(
+        "\t; ASLAM_STRIP_LIVE_END\n\t;;#ASMEND\n\ts_endpgm\n\"\"\"", ""))
+    assert any("vacuous" in x[2] for x in g.scan(str(p)))
+
+
+def test_vmcnt_protocol_detector(tmp_path):
+    """the compiler-generated vector-memory instructions inside the hand-counted sweeps must be exactly the stores the s_waitcnt vmcnt counts
+    assume: one extra store, a scratch reload or a compiler-generated vmcnt wait fails the build"""
+    import check_vmcnt_protocol as g
+
+    ok = tmp_path / "ok.s"
+    ok.write_text(STRIP % ("\tv_add_f32_e32 v1, v2, v3", ""))
+    f, checked = g.scan(str(ok))
+    assert not f and len(checked) == 2, (f, checked)
+    for name, extra, frag in (("store.s", "\tglobal_store_dwordx4 v[0:1], v[2:5], off", "differ"),
+                              ("reload.s", "\tscratch_load_dword v7, off, off offset:16 ; 4-byte Folded Reload", "unexpected"),
+                              ("wait.s", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "s_waitcnt vmcnt")):
+        p = tmp_path / name
+        p.write_text(STRIP % ("\tv_add_f32_e32 v1, v2, v3", extra))
+        f, _ = g.scan(str(p))
+        assert f and any(frag in x[2] for x in f), (name, f)

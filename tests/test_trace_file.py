@@ -96,5 +96,35 @@ def test_spin_semantics():
     assert list(tr.obs_new[0]) == [0, 1, 0] and list(tr.n_obs[0]) == [0, 2, 0]
     assert np.array_equal(tr.obs[0, 1], np.array([[1.5, 0.25], [2.5, 0.5]], np.float32))
     assert list(tr.dt[0]) == [1.0, 1.0, 1.0]
-    fast = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(100e9))
-    assert fast.dt[0, -1] == np.float32(0.25) or fast.dt[0, -1] == np.float32(1.0)
+
+
+def test_delta_time_is_the_reference_arithmetic_with_a_binary32_last_time():
+    """`float delta_time = std::min(ros::Time::now().toSec() - last_time, 1.0)` with `last_time` a FLOAT member (ekf.h:98, ekf.cpp:80-81)
+    that initialize() seeds with the construction time (ekf.cpp:54).  Exact expected values, derived by hand:
+
+    * sim-time stamps, 4 Hz from t = 100 s: every spin time 100.25 k is exact in binary32, so past the gate dt = 0.25 exactly; the first
+      callback past the gate measures from the construction time (no earlier callback advanced last_time: they returned at the gate);
+    * epoch-sized stamps (1.7e9 s = 13 281 250 x 128: exact in binary32, whose spacing there is 128 s): last_time = float(now) rounds every
+      spin time of the test back to 1.7e9, so the reference's delta_time GROWS by a spin period per callback until the 1.0 clamp --
+      0.5, 0.75, 1.0, 1.0 -- where a double last_time would give 0.25 every time."""
+    hdr = ",".join(["%time"] + list(rosdump.ODOM_FIELDS))
+
+    def dumps(base_s, n):
+        rows = [",".join([str(int(round((base_s + 0.25 * k + 0.1) * 1e9)))] + [repr(float(k))] * 8) for k in range(n)]
+        lms = "%time,field.x0,field.y0\n" + f"{int(round((base_s + 0.05) * 1e9))},1.5,2.5\n"
+        return "\n".join([hdr] + rows) + "\n", lms
+
+    odom, lms = dumps(100.0, 6)   # odometry k arrives at 100.1 + 0.25 k: spin k + 1 (100.25 (k + 1)) delivers it; landmarks before the first spin
+    tr = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(100e9))
+    assert tr.T == 6 and list(tr.obs_new[0]) == [1, 0, 0, 0, 0, 0]
+    assert tr.dt.dtype == np.float32 and [float(x) for x in tr.dt[0]] == [0.25] * 6
+    late = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(100e9), t_init_ns=int(99.5e9))  # node constructed 0.5 s before the first spin period
+    assert [float(x) for x in late.dt[0]] == [0.75] + [0.25] * 5
+    base = 1_700_000_000.0
+    assert float(np.float32(base)) == base and float(np.float32(base + 1.5)) == base
+    odom, lms = dumps(base, 5)
+    ep = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(base) * 10**9)
+    assert [float(x) for x in ep.dt[0]] == [0.25, 0.5, 0.75, 1.0, 1.0]
+    # a node constructed at an epoch time whose binary32 image lies AHEAD of the clock: the reference's delta_time is negative
+    ahead = rosdump.to_trace(odom, lms, freq_hz=4.0, t_start_ns=int(base) * 10**9, t_init_ns=int(base + 100) * 10**9)
+    assert float(np.float32(base + 100)) == base + 128 and float(ahead.dt[0, 0]) == 0.25 - 128.0

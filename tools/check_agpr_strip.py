@@ -12,7 +12,10 @@ copies).  Such a use INSIDE a sweep would silently corrupt V / L.  The sweep bra
     whose blocks the compiler lays out between the two), or
   * `large_trsm_pipe`, whose strip is live from its first to its last instruction, references one anywhere outside inline
     assembly, or
-  * BEGIN / END markers do not pair up (a block-layout change that would make the linear-order reading unsound).
+  * BEGIN / END markers do not pair up, or a branch crosses a BEGIN .. END range in either direction (a cold block -- the taken side of a
+    `__builtin_expect(..., 0)`, a spin loop -- laid out behind the END marker would run with the strip live and not be scanned: the
+    linear-order reading would be unsound), or
+  * one of the four strip kernels (REQUIRED) has no marker pair at all (the guard would be vacuous for it).
 
     python tools/check_agpr_strip.py file.s [file.s ...]
 """
@@ -21,13 +24,17 @@ import sys
 
 KERNEL = re.compile(r"^([A-Za-z_][\w.$]*):\s*;\s*@")
 AGPR = re.compile(r"(?<![\w.])a(\d+|\[\d+:\d+\])(?![\w])|v_accvgpr_")
-WHOLE_KERNEL = ("large_trsm_pipe",)  # strip live throughout
+WHOLE_KERNEL = ("large_trsm_pipe", "large_trsm_bf16")  # one sweep per workgroup: nothing of the compiler's may touch an AGPR anywhere in the kernel
+REQUIRED = ("large_trsm_pipe", "large_chol_resident", "large_trsm_bf16", "large_chol_bf16")  # every kernel that keeps a strip
+LABEL = re.compile(r"^(\.LBB\w+):")
+BRANCH = re.compile(r"^\s*(s_cbranch_\w+|s_branch)\s+(\.LBB\w+)")
 
 
 def scan(path):
     findings = []
     kernel, in_asm, live, begins, ends = None, False, False, 0, 0
     seen_markers = {}
+    labels, branches = {}, []  # (kernel, label) -> (line, inside a live range); (kernel, line, inside, target, text)
     for i, ln in enumerate(open(path, errors="replace").read().splitlines(), 1):
         m = KERNEL.match(ln)
         if m:
@@ -56,14 +63,24 @@ def scan(path):
             continue
         if in_asm:
             continue
+        m = LABEL.match(ln)
+        if m:
+            labels[(kernel, m.group(1))] = (i, live)
+        m = BRANCH.match(ln)
+        if m:
+            branches.append((kernel, i, live, m.group(2), ln.strip()))
         code = ln.split(";")[0]
         if not code.strip() or code.lstrip().startswith("."):
             continue
         whole = any(w in kernel for w in WHOLE_KERNEL)
         if (live or whole) and AGPR.search(code):
             findings.append((kernel, i, "compiler-generated AGPR use while the hand-allocated strip is live", ln.strip()))
-    if not any("large_trsm_pipe" in k for k in seen_markers) or not any("large_chol_resident" in k for k in seen_markers):
-        findings.append(("?", 0, "markers not found in large_trsm_pipe / large_chol_resident: the guard would be vacuous", ""))
+    for k, i, inside, target, text in branches:
+        if k in seen_markers and (k, target) in labels and labels[(k, target)][1] != inside:
+            findings.append((k, i, "branch %s an ASLAM_STRIP_LIVE range (target at line %d): the linear-order reading is unsound" % ("out of" if inside else "into", labels[(k, target)][0]), text))
+    for r in REQUIRED:
+        if not any(r in k for k in seen_markers):
+            findings.append((r, 0, "no ASLAM_STRIP_LIVE_BEGIN / END markers found in this kernel: the guard would be vacuous", ""))
     return findings
 
 
