@@ -448,9 +448,9 @@ class Core:
         return npad.value, nbytes.value
 
     def kernel_info(self):
-        name = ctypes.create_string_buffer(128)
+        name = ctypes.create_string_buffer(192)
         g, b, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        _chk(core_lib().aslam_kernel_info(self._h, name, 128, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
+        _chk(core_lib().aslam_kernel_info(self._h, name, 192, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
         return {"name": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
 
     def launch_info(self):

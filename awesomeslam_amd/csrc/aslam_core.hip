@@ -364,9 +364,15 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         else if (!right) // (large_right_step has solved the rows of G on its way)
                                 hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         if (c->syrk_running)
-                                hipLaunchKernelGGL(large_syrk_bf16x3<2>, syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
+                                hipLaunchKernelGGL((large_syrk_bf16x3<2>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
                         else
-                                hipLaunchKernelGGL(large_syrk_bf16x3<0>, syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
+                                hipLaunchKernelGGL((large_syrk_bf16x3<0>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
+                        // X += V q (+ the diagonal and the pose columns of V V^T in binary64) BEHIND the syrk on the same stream.  Round 4 tried the two ways of
+                        // running it next to the syrk -- its workgroups inside the syrk launch, and on a side stream of its own (the two write disjoint entries
+                        // of P) -- and both were slower: 2436 us against 1997 + 324 per 256 filters, and 31.7 k against 36.4 k filter-steps/s
+                        // (profiles/r04_experiments.md section 1)
+                        hipLaunchKernelGGL((large_x_update_rows<MODE>), dim3((NP + 4 * XU_ROWS - 1) / (4 * XU_ROWS), gb), dim3(256), 0, g.st, g.dv, vv, s, nsteps, g.poses,
+                                           g.dims, g.skip);
                 }
                 else
                 {
@@ -377,10 +383,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         }
                         hipLaunchKernelGGL(large_syrk<T>, syrk_grid, dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                 }
-                if constexpr (sizeof(T) == 4)
-                        hipLaunchKernelGGL((large_x_update_rows<MODE>), dim3((NP + 4 * XU_ROWS - 1) / (4 * XU_ROWS), gb), dim3(256), 0, g.st, g.dv, vv, s, nsteps,
-                                           g.poses, g.dims, g.skip);
-                else
+                if constexpr (sizeof(T) == 8)
                         hipLaunchKernelGGL((large_x_update<T, MODE, false>), dim3((NP + 3) / 4, gb), dim3(256), 0, g.st, g.dv, g.v, s, nsteps, g.poses, g.dims,
                                            g.skip);
         };
@@ -1248,16 +1251,19 @@ int aslam_kernel_info(aslam_ctx *c, char *name, int name_cap, int *grid, int *bl
 {
         if (!c)
                 return fail(ASLAM_ERR_ARG, "null context");
-        char buf[128];
+        char buf[192];
         size_t lds = 0;
         if (c->large)
         {
                 const bool resident = c->chol_resident >= 0 ? c->chol_resident != 0 : c->cfg.batch >= aslam_ctx::CHOL_RESIDENT_MIN_BATCH;
-                if (c->cfg.dtype == ASLAM_F32 && resident && c->lv32.Lpl)
-                        std::snprintf(buf, sizeof(buf), "large_chol_bf16 + large_trsm_bf16 + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)", c->large_groups);
-                else if (c->cfg.dtype == ASLAM_F32 && resident)
-                        std::snprintf(buf, sizeof(buf), "large_chol_resident + large_trsm_pipe<%d> + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)",
-                                      (int)LARGE_NB_MAX, c->large_groups);
+                if (c->cfg.dtype == ASLAM_F32 && resident)
+                {
+                        // the names say which pipe each kernel's products run on (bench.py prices them from this string): bit 1 of bf16_pipe = the
+                        // Cholesky, bit 0 = the TRSM on the bf16 matrix pipe; the X update rides in the syrk launch
+                        const bool chol16 = c->lv32.Lpl && (c->bf16_pipe & 2), trsm16 = c->lv32.Lpl && (c->bf16_pipe & 1);
+                        std::snprintf(buf, sizeof(buf), "%s + %s + large_syrk_bf16x3 (6-launch chain per callback, %d stream groups)",
+                                      chol16 ? "large_chol_bf16" : "large_chol_resident", trsm16 ? "large_trsm_bf16" : "large_trsm_pipe<17>", c->large_groups);
+                }
                 else if (c->cfg.dtype == ASLAM_F32 && c->right_step && c->lv32.Vw)
                         std::snprintf(buf, sizeof(buf), "large_right_step + large_syrk_bf16x3 (%d-launch chain per callback: one right-looking launch per block column)", 5 + c->NP / LB);
                 else if (c->cfg.dtype == ASLAM_F32)

@@ -867,6 +867,13 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
 /// as B x A^T so that a lane holds four consecutive columns of a row) and its NEW value is stored, transposed, into the upper triangle -- no
 /// read of the upper triangle, and P stays exactly symmetric.  The slab of V is split into its three bf16 planes by the VALU on the way into LDS (8 bytes per thread, row and plane; unpadded 64-byte rows with XOR-swizzled k-groups),
 /// the operand of an MFMA is ONE 16-byte read (row l & 15, k = 8 (l >> 4) .. + 7).
+///
+/// The X update (large_x_update_rows: X += V q, the diagonal and the pose columns of V V^T in binary64) follows this kernel on the same stream.  This kernel
+/// never touches the entries of P the other one writes (pose columns, pose rows, diagonal), so the two COULD run side by side -- round 4 measured both
+/// ways (the X update's workgroups inside this launch: 2436 us against 1997 + 324 per 256 filters; on a side stream: 31.7 k against 36.4 k filter-steps/s)
+/// and both lose: at this kernel's register footprint the latency-bound X-update workgroups take slots while the matrix pipes idle, and next to it they
+/// fight it for L2 (profiles/r04_experiments.md section 1).
+constexpr int XU_ROWS = 8;
 template <int DIAG = 0>
 __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
 {
@@ -1086,15 +1093,11 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                 return;
         }
         const bool mirror = (jt < rt || wc < wr);
-        // The DIAGONAL of V V^T and its three POSE columns are formed with binary64 accumulation by large_x_update<.., SLIM> (see there) and are left
-        // alone here: the pose columns by clearing their sums (columns 0..2 = registers 0..2 of lane group 0 in the first column tile of tile
-        // column 0: the read-modify-write below then stores the old values back), the diagonal by skipping it.
-        if (jt == 0 && wc == 0 && lg == 0)
-        {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                        acc[u][0][0] = acc[u][0][1] = acc[u][0][2] = 0.f;
-        }
+        // The DIAGONAL of V V^T and its three POSE columns (and their mirror image, the pose rows) are formed with binary64 accumulation by the X-update
+        // kernel (large_x_update_rows) and are NOT TOUCHED here -- not even read and stored back (a store-back of an old value would tie the order of the two
+        // kernels).  Pose columns 0..2 = registers 0..2 of lane group 0 in the first
+        // column tile of tile column 0 (posecols below: only its column 3 is updated, by 8-byte accesses); the diagonal is skipped element-wise.
+        const bool posecols_lane = (jt == 0 && wc == 0 && lg == 0);
         {
                 // The K loop multiplies B x A^T (operands swapped), so a lane's four registers are four consecutive COLUMNS of one row of the
                 // lower tile: 32 contiguous bytes, two 16-byte loads and stores per 16x16 tile; the mirror image is the strided side (four
@@ -1110,12 +1113,14 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                                 const int col0 = jt * TB + wc + 16 * v + 4 * lg;
                                 if (row >= n || col0 >= n || (diagq && v > u))
                                         continue;
-                                if (diagq && v == u)
+                                const bool posecols = posecols_lane && v == 0; // this lane's four columns are 0 .. 3
+                                if ((diagq && v == u) || posecols)
                                 {
-                                        // 16x16 tile on the diagonal: the elements J < I, each with its mirror image (J == I: large_x_update)
+                                        // 16x16 tile on the diagonal: the elements J < I, each with its mirror image (J == I: the X update);
+                                        // columns 0 .. 3: column 3 only
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
-                                                if (col0 + r < row)
+                                                if (col0 + r < row && !(posecols && r < 3) && col0 + r < n)
                                                 {
                                                         double *pe = P + (size_t)row * NP + col0 + r;
                                                         const double pn = *pe - (double)acc[u][v][r];
@@ -1267,17 +1272,14 @@ __global__ __launch_bounds__(256) void large_x_update(DevView d, LargeView<T> lv
 /// every row of V is multiplied with -- q and the pose rows of V -- staged ONCE per workgroup in LDS (17 KB) for the XU_ROWS x 4 rows its waves
 /// walk.  With a wave per row and the shared rows read from memory every wave issued 25 loads of 16 bytes per lane for 4 KB of new data: 391 us
 /// per 256 filters against 217 us for round 2's single product (profiles/r03_experiments.md).  grid (ceil(NP / (4 XU_ROWS)), B), 256 threads.
-constexpr int XU_ROWS = 8;
+/// the body: workgroup `xb` of filter `b` (32 rows); sh = 4 x LARGE_NP_MAX floats of LDS
 template <int MODE>
-__global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<float> lv, int s, int nsteps, double *poses_out, int32_t *dims_out, const int *skipped)
+__device__ __forceinline__ void x_update_rows_body(float (*sh)[LARGE_NP_MAX], const DevView &d, const LargeView<float> &lv, int b, int xb, int n, int s, int nsteps,
+                                                   double *poses_out, int32_t *dims_out)
 {
-        __shared__ __attribute__((aligned(16))) float sh[4][LARGE_NP_MAX]; // q, pose rows 0 .. 2 of V
-        const int b = blockIdx.y;
-        if (skipped[b])
-                return;
-        const int n = d.n[b], NP = lv.NP;
+        const int NP = lv.NP;
         const int tid = threadIdx.x, lane = tid & 63;
-        if ((int)blockIdx.x * 4 * XU_ROWS >= n)
+        if (xb * 4 * XU_ROWS >= n)
                 return;
         const float *G = lv.G + (size_t)b * NP * NP;
         for (int j = 4 * tid; j < NP; j += 4 * 256)
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<
         }
         __syncthreads();
         double *P = lv.P + (size_t)b * NP * NP;
-        const int a0 = (blockIdx.x * 4 + (tid >> 6)) * XU_ROWS;
+        const int a0 = (xb * 4 + (tid >> 6)) * XU_ROWS;
         constexpr int NPASS = 5; // 5 x 64 lanes x 4 columns = 1280 >= LARGE_NP_MAX
         auto load_row = [&](f4 (&v)[NPASS], int a) {
                 const float *vr = G + (size_t)min(a, n - 1) * NP;
@@ -1359,6 +1361,17 @@ __global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<
                         }
                 }
         }
+}
+
+/// grid (ceil(NP / (4 XU_ROWS)), B), 256 threads
+template <int MODE>
+__global__ __launch_bounds__(256) void large_x_update_rows(DevView d, LargeView<float> lv, int s, int nsteps, double *poses_out, int32_t *dims_out, const int *skipped)
+{
+        __shared__ __attribute__((aligned(16))) float sh[4][LARGE_NP_MAX]; // q, pose rows 0 .. 2 of V
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        x_update_rows_body<MODE>(sh, d, lv, b, (int)blockIdx.x, d.n[b], s, nsteps, poses_out, dims_out);
 }
 } // namespace aslam
 
