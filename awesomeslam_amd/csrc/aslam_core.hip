@@ -364,9 +364,9 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         else if (!right) // (large_right_step has solved the rows of G on its way)
                                 hipLaunchKernelGGL(large_trsm_pipe<LARGE_NB_MAX>, dim3(8 * ((gb + 7) / 8) * NB), dim3(256), 0, g.st, g.dv, g.v, gb, g.skip);
                         if (c->syrk_running)
-                                hipLaunchKernelGGL((large_syrk_bf16x3<2>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
+                                hipLaunchKernelGGL((large_syrk_bf16x3<2>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, LPlanes{nullptr}, gb, g.skip);
                         else
-                                hipLaunchKernelGGL((large_syrk_bf16x3<0>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, gb, g.skip);
+                                hipLaunchKernelGGL((large_syrk_bf16x3<0>), syrk_grid, dim3(256), 0, g.st, g.dv, vv, LPlanes{nullptr}, gb, g.skip);
                         // X += V q (+ the diagonal and the pose columns of V V^T in binary64) BEHIND the syrk on the same stream.  Round 4 tried the two ways of
                         // running it next to the syrk -- its workgroups inside the syrk launch, and on a side stream of its own (the two write disjoint entries
                         // of P) -- and both were slower: 2436 us against 1997 + 324 per 256 filters, and 31.7 k against 36.4 k filter-steps/s

@@ -874,8 +874,14 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
 /// and both lose: at this kernel's register footprint the latency-bound X-update workgroups take slots while the matrix pipes idle, and next to it they
 /// fight it for L2 (profiles/r04_experiments.md section 1).
 constexpr int XU_ROWS = 8;
-template <int DIAG = 0>
-__global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView<float> lv, int nfilters, const int *skipped)
+///
+/// PL = 1 (round 4; the default chain): V arrives ALREADY SPLIT -- large_trsm_bf16 stores the three bf16 planes of every solved block next to the binary32 V
+/// (`vpl`: [B][3][NP][NP], the columns of every 64-block permuted as in LPlanes; the permutation stays inside a 32-column half, and a slab's contraction
+/// order is the same for both operands) -- and a slab goes global -> LDS by LDS-DMA (twelve 1-KiB pieces per wave: 16 rows x 64 bytes each, the k-group
+/// swizzle applied on the source side): no staging registers, no VALU split (176 instructions per thread and slab: each element of V was split ~ 17 times,
+/// once per tile that reads it), no ds_write.  tools/ubench/syrk_bench.hip: K loop 1.81 -> see profiles/r04_experiments.md.
+template <int DIAG = 0, int PL = 0>
+__global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView<float> lv, LPlanes vpl, int nfilters, const int *skipped)
 {
         constexpr int TB = 128, KC = 32;
         constexpr int LDB = KC; // bf16 per LDS row: 64 bytes, unpadded; the four 16-byte k-groups of a row are XOR-swizzled with (row & 15) >> 2, which
@@ -923,12 +929,42 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                         acc[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
         f4 ta[NPASS], tb[NPASS];
         auto fetch = [&](int kc) {
+                if constexpr (PL)
+                        return;
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q)
                 {
                         ta[q] = *reinterpret_cast<const f4 *>(Ap[q] + kc);
                         tb[q] = *reinterpret_cast<const f4 *>(Bp[q] + kc);
                 }
+        };
+        // PL: the LDS-DMA of a slab.  Piece = 16 rows x 64 bytes of one plane: lane l = row l >> 2, LDS chunk l & 3, which holds logical k-group
+        // (l & 3) ^ ((row & 15) >> 2) = (l & 3) ^ (l >> 4) (the swizzle of the operand reads).  Wave w moves pieces 2 w, 2 w + 1 (rows 32 w .. 32 w + 31) of the
+        // three planes of A and of B.  Rows past NP read the next plane / zeros (buffer bounds): finite, and their results are never stored.
+        typedef __attribute__((address_space(3))) unsigned short lds_us;
+        const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(PL ? (void *)vpl.Lq(b, NP) : (void *)nullptr, 0, (int)(LPlanes::per_filter(NP) * 2), 0x00020000);
+        const unsigned dma_vo = (unsigned)(((lane >> 2) * NP) * 2 + (((lane & 3) ^ (lane >> 4)) * 16));
+        const unsigned ldsA = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)&As[0][0] + (unsigned)wave * 2048u));
+        const unsigned ldsB = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_us *)&Bs[0][0] + (unsigned)wave * 2048u));
+        auto dma_slab = [&](int kc) {
+                const unsigned plane_b = (unsigned)(NP * NP * 2);
+                const unsigned soA = (unsigned)__builtin_amdgcn_readfirstlane(((rt * TB + 32 * wave) * NP + kc) * 2);
+                const unsigned soB = (unsigned)__builtin_amdgcn_readfirstlane(((jt * TB + 32 * wave) * NP + kc) * 2);
+                const unsigned r16 = (unsigned)(16 * NP * 2);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                        {
+                                asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                                             :
+                                             : "s"(ldsA), "n"(p * TB * LDB * 2 + jj * 1024), "v"(dma_vo), "s"(vrs), "s"(soA + (unsigned)p * plane_b + (unsigned)jj * r16)
+                                             : "m0", "scc", "memory");
+                                asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                                             :
+                                             : "s"(ldsB), "n"(p * TB * LDB * 2 + jj * 1024), "v"(dma_vo), "s"(vrs), "s"(soB + (unsigned)p * plane_b + (unsigned)jj * r16)
+                                             : "m0", "scc", "memory");
+                        }
         };
         // four floats -> their three bf16 planes: x = h + m + l up to 2^-25 |x|.  Round to nearest at every level (v_cvt_pk_bf16_f32): with
         // truncated pieces, which all carry the sign of x, the dropped terms a2 b3 + a3 b2 have the sign of the product, V V^T comes out
@@ -966,13 +1002,30 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
         fetch(0);
         for (int kc = 0; kc < kend; kc += KC)
         {
-#pragma unroll
-                for (int q = 0; q < NPASS; ++q)
+                if constexpr (PL)
                 {
-                        stash(As, s_off + RPP * q * LDB, ta[q]);
-                        stash(Bs, s_off + RPP * q * LDB, tb[q]);
+                        // single-buffered: the slab is fetched behind the barrier that ended the previous slab's reads; the two other workgroups of the CU
+                        // multiply while this one waits for its pieces
+                        dma_slab(kc);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                __syncthreads();
+                else if (!(DIAG & 4) || kc == 0) // (DIAG 4, tools/ubench/syrk_bench.hip: timing without the split and the LDS stash -- stale LDS, wrong results)
+                {
+#pragma unroll
+                        for (int q = 0; q < NPASS; ++q)
+                        {
+                                stash(As, s_off + RPP * q * LDB, ta[q]);
+                                stash(Bs, s_off + RPP * q * LDB, tb[q]);
+                        }
+                }
+                else
+                {
+#pragma unroll
+                        for (int q = 0; q < NPASS; ++q)
+                                asm volatile("" ::"v"(ta[q]), "v"(tb[q])); // the loads stay
+                }
+                if (!(DIAG & 32)) // (DIAG 32: timing without the barriers -- racy)
+                        __syncthreads();
                 if (kc + KC < kend)
                         fetch(kc + KC);
                 // two column tiles of the wave's 64x64 at a time: 24 operand registers instead of 48 (three workgroups per CU).
@@ -984,7 +1037,10 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                 // (tools/ubench/syrk_accum.hip).  Interior tiles (the bulk) take the branch-free path, where the addition of a pair of
                 // temporaries is issued behind the MFMAs of the NEXT pair.
 #define ASLAM_MM(t, bb, aa, c) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bb), __builtin_bit_cast(bf8, aa), c, 0, 0, 0)
-                if (full)
+                if (DIAG & 8) // (timing without the MFMAs)
+                {
+                }
+                else if (full)
                 {
 #pragma unroll
                         for (int vh = 0; vh < 4; vh += 2)
@@ -994,7 +1050,12 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                                 for (int v = 0; v < 2; ++v)
 #pragma unroll
                                         for (int p = 0; p < 3; ++p)
-                                                bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
+                                        {
+                                                if (DIAG & 16) // (timing without the operand reads)
+                                                        asm volatile("" : "=v"(bq[v][p]));
+                                                else
+                                                        bq[v][p] = *reinterpret_cast<const u4 *>(&Bs[p][b_off + 16 * (vh + v) * LDB]);
+                                        }
                                 f4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f}; // the previous row tile's pair, not yet added
 #pragma unroll
                                 for (int u = 0; u < 4; ++u)
@@ -1002,7 +1063,12 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                                         u4 ap[3];
 #pragma unroll
                                         for (int p = 0; p < 3; ++p)
-                                                ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+                                        {
+                                                if (DIAG & 16)
+                                                        asm volatile("" : "=v"(ap[p]));
+                                                else
+                                                        ap[p] = *reinterpret_cast<const u4 *>(&As[p][a_off + 16 * u * LDB]);
+                                        }
                                         f4 ta, tb;
                                         ASLAM_MM(ta, bq[0][0], ap[2], ((f4){0.f, 0.f, 0.f, 0.f}));
                                         ASLAM_MM(tb, bq[1][0], ap[2], ((f4){0.f, 0.f, 0.f, 0.f}));
@@ -1075,7 +1141,8 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
                         }
                 }
 #undef ASLAM_MM
-                __syncthreads();
+                if (!(DIAG & 32)) // (DIAG 32: timing without the barriers -- racy)
+                        __syncthreads();
         }
         if (idle)
                 return;

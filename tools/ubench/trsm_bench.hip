@@ -495,12 +495,12 @@ int main(int argc, char **argv)
                 const dim3 grid(8 * (ntile * (ntile + 1) / 2) * ((B + 7) / 8));
                 const double sf = (ntile * (ntile + 1) / 2 - ntile * 0.25) * 2.0 * 128 * 128 * 1056 * B;
                 // (round 2 also timed large_syrk_f32p64 here, the fp32-MFMA form: 3.06 ms per 256 filters, K loop 2.7 ms; removed in round 3)
-                const float mb = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<0>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                const float mb = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<0>), grid, dim3(256), 0, 0, d, lv, LPlanes{nullptr}, B, dskip); }, 5);
                 std::printf("  syrk_bf16x3      %8.3f ms for %d filters = %6.1f T fp32-equivalent FLOP/s executed\n", mb, B, sf / (mb * 1e-3) / 1e12);
-                const float mbk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<1>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                const float mbk = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<1>), grid, dim3(256), 0, 0, d, lv, LPlanes{nullptr}, B, dskip); }, 5);
                 std::printf("  syrk_bf16x3 without the read-modify-write of P      %8.3f ms\n", mbk);
-                const float mb2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<2>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
-                const float mbk2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<3>), grid, dim3(256), 0, 0, d, lv, B, dskip); }, 5);
+                const float mb2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<2>), grid, dim3(256), 0, 0, d, lv, LPlanes{nullptr}, B, dskip); }, 5);
+                const float mbk2 = time_ms([&]() { hipLaunchKernelGGL((large_syrk_bf16x3<3>), grid, dim3(256), 0, 0, d, lv, LPlanes{nullptr}, B, dskip); }, 5);
                 std::printf("  syrk_bf16x3 with round 2's running accumulator (no per-slab temporaries)  %8.3f ms, without the read-modify-write %8.3f ms\n", mb2, mbk2);
         }
         return 0;
