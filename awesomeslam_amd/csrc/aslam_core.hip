@@ -78,6 +78,8 @@ struct aslam_ctx
         int chol_resident = -1;
         int right_step = 1;   // binary32 mode below the resident batch: the right-looking one-launch-per-block-column chain (large_right_step); ASLAM_RIGHT_STEP=0: the left-looking chain of rounds 1 - 2 (potrf + panel launches, large_trsm_pipe)
         int bf16_pipe = 3;    // binary32 mode, resident Cholesky: Cholesky and TRSM on the bf16 matrix pipe (large_chol_bf16 + large_trsm_bf16, ekf_large_trsm16.h); ASLAM_BF16_PIPE=0: the fp32-MFMA kernels
+        int keep_l32 = 0;     // ASLAM_KEEP_L32=1 (tests/manual/large_residuals.py reads L back): large_chol_bf16 also stores the off-diagonal blocks of L in binary32
+        int gs_tiles = 0;     // G, S from the lower block triangle of P (large_build_GS_tiles); ASLAM_GS_TILES=0: the row-pair kernel that reads all of P (large_build_GS) -- bit-identical results
         int syrk_running = 0; // diagnostic (ASLAM_SYRK_RUNNING=1): round 2's accumulation order in large_syrk_bf16x3 (profiles/r03_experiments.md)
         static constexpr int CHOL_RESIDENT_MIN_BATCH = 32;
         hipStream_t aux[LARGE_GROUPS - 1] = {};
@@ -326,7 +328,10 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
         auto chain = [&](const Group &g, int s) {
                 const int gb = g.nb;
                 hipLaunchKernelGGL(fk, dim3(gb), dim3(SMALL_WG), lds, g.st, g.dv, g.v, t0 + s, s, nsteps, g.poses, g.dims, sa, g.skip);
-                hipLaunchKernelGGL(large_build_GS<T>, dim3(1 + (NP / 2 + GS_ROW_PAIRS - 1) / GS_ROW_PAIRS, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                if (c->gs_tiles)
+                        hipLaunchKernelGGL(large_build_GS_tiles<T>, dim3(NB * (NB + 1) / 2, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
+                else
+                        hipLaunchKernelGGL(large_build_GS<T>, dim3(1 + (NP / 2 + GS_ROW_PAIRS - 1) / GS_ROW_PAIRS, gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                 const int ntile = (NP + 127) / 128;
                 const dim3 syrk_grid(8 * (ntile * (ntile + 1) / 2) * ((gb + 7) / 8));
                 LargeView<T> vv = g.v; // what the consumers of V read
@@ -339,7 +344,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                         const bool right = !resident && c->right_step && g.v.Vw != nullptr;
                         const bool pipe16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 1), chol16 = resident && g.v.Lpl != nullptr && (c->bf16_pipe & 2);
                         if (chol16)
-                                launch_chol_bf16(g.dv, g.v, gb, g.skip, g.st);
+                                launch_chol_bf16(g.dv, g.v, gb, g.skip, g.st, !pipe16 || c->keep_l32); // (the bf16 TRSM reads L through its planes only)
                         else if (resident)
                                 hipLaunchKernelGGL(large_chol_resident<LARGE_NB_MAX>, dim3(gb), dim3(256), 0, g.st, g.dv, g.v, g.skip);
                         else if (right)
@@ -553,6 +558,10 @@ int aslam_create(const aslam_config *cfg, aslam_ctx **out)
                         c->large_groups = std::max(1, std::min((int)aslam_ctx::LARGE_GROUPS, std::atoi(e)));
                 if (const char *e = std::getenv("ASLAM_CHOL_RESIDENT"))
                         c->chol_resident = std::atoi(e) != 0;
+                if (const char *e = std::getenv("ASLAM_KEEP_L32"))
+                        c->keep_l32 = std::atoi(e) != 0;
+                if (const char *e = std::getenv("ASLAM_GS_TILES"))
+                        c->gs_tiles = std::atoi(e) != 0;
                 if (const char *e = std::getenv("ASLAM_SYRK_RUNNING"))
                         c->syrk_running = std::atoi(e) != 0;
                 if (const char *e = std::getenv("ASLAM_RIGHT_STEP"))

@@ -11,10 +11,13 @@
 
 namespace aslam
 {
-void launch_chol_bf16(const DevView &dv, const LargeView<float> &lv, int nfilters, const int *skipped, hipStream_t st)
+void launch_chol_bf16(const DevView &dv, const LargeView<float> &lv, int nfilters, const int *skipped, hipStream_t st, bool f32out)
 {
         const LPlanes pl = {lv.Lpl};
-        hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX>), dim3(nfilters), dim3(256), 0, st, dv, lv, pl, skipped);
+        if (f32out)
+                hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX, true>), dim3(nfilters), dim3(256), 0, st, dv, lv, pl, skipped);
+        else
+                hipLaunchKernelGGL((large_chol_bf16<LARGE_NB_MAX, false>), dim3(nfilters), dim3(256), 0, st, dv, lv, pl, skipped);
 }
 
 void launch_trsm_bf16(const DevView &dv, const LargeView<float> &lv, int nfilters, const int *skipped, hipStream_t st)

@@ -491,6 +491,201 @@ template <typename T> __global__ __launch_bounds__(256) void large_build_GS(DevV
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+/// The same G and S, bit for bit, from the LOWER BLOCK TRIANGLE of P alone (round 4).  P is symmetric (large_syrk* store the mirror image of every
+/// entry they compute, the predict writes rows and columns 0, 1 alike), so the 64x64 block (I, J), J <= I, serves three outputs:
+///     G(I, J)  = P(I, :) H^T restricted to the columns of J                       (rows of the block)
+///     G(J, I)  = P(J, :) H^T restricted to the columns of I, with P(J, I) = P(I, J)^T   (columns of the block, read transposed from LDS)
+///     S(I, J)  = H(I, :) G(:, J) + R                                               (needs G(I +- 1 row, J) and G(0..2, J), kept in binary64 in LDS)
+/// large_build_GS read all of P (8.4 MB per filter at n = 1027) to write G and the lower block triangle of S; this reads 4.4 MB: the kernel is
+/// HBM-bound, 16.6 -> 12.4 MB per filter and callback.  H couples landmark column pair (c_odd, c_even) = (3 + 2 j, 4 + 2 j) only to the pose and to
+/// itself (ekf.cpp:117-134), so an entry needs its own 2-column (2-row) pair -- pairs straddle the 64-blocks, hence the one-element halo around the
+/// block -- and the pose columns of its row.  Every expression is evaluated in the order large_build_GS uses (no contraction): G and S come out
+/// bit-identical, which tests/test_gpu_large.py::test_tiled_GS_is_bit_identical checks through the diagnostic read-back.
+/// grid (NB (NB + 1) / 2, B) with NB = NP / 64, 256 threads; 40 KB of LDS (the block with its halo, 66 x 67 doubles, and the small vectors): four
+/// workgroups per CU.  A thread forms, for its entry (r, c), G(r, c) AND the G entry of the other row of r's pair (the halo rows make that possible at
+/// the block's edges), so S(r, c) needs nothing from other threads; the first version kept G(I +- 1, J) in LDS in binary64 (76 KB, two workgroups per CU)
+/// and indexed by division: 2.0 ms per 256 filters against 0.81 - 0.94 ms for large_build_GS (profiles/r04_experiments.md section 3).
+struct GsTilesLds
+{
+        static constexpr int HB = LB + 2, PLD = HB + 1; // block + halo; row stride 67 doubles: the transposed reads are conflict-free
+        double Pt[HB][PLD];          // P(64 I - 1 + r, 64 J - 1 + c)
+        double tI[HB][4], tJ[LB][4]; // pose columns P(a, 0..2) of the rows of I (with halo) and of J
+        double cI[HB][2], cJ[LB][2]; // (u, v) of H for the rows of I (with halo: the partner rows) and the columns of J: (h00, h01) on odd, (h10, h11) on even indices
+        double P3[3][HB], G3[3][LB], P33[3][4]; // P(0..2, 64 J - 1 + c), G(0..2, 64 J + c), P(0..2, 0..2)
+};
+template <typename T> __global__ __launch_bounds__(256) void large_build_GS_tiles(DevView d, LargeView<T> lv, const int *skipped)
+{
+        constexpr int HB = GsTilesLds::HB;
+        __shared__ GsTilesLds sh;
+        auto &Pt = sh.Pt;
+        auto &tI = sh.tI;
+        auto &tJ = sh.tJ;
+        auto &cI = sh.cI;
+        auto &cJ = sh.cJ;
+        auto &P3 = sh.P3;
+        auto &G3 = sh.G3;
+        auto &P33 = sh.P33;
+        const int b = blockIdx.y;
+        if (skipped[b])
+                return;
+        const int n = d.n[b], NP = lv.NP;
+        const int nb = large_blocks(n);
+        const int tl = blockIdx.x;
+        int I = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while ((I + 1) * (I + 2) / 2 <= tl)
+                ++I;
+        while (I * (I + 1) / 2 > tl)
+                --I;
+        const int J = tl - I * (I + 1) / 2;
+        if (I >= nb)
+                return;
+        const double *P = lv.P + (size_t)b * NP * NP;
+        T *G = lv.G + (size_t)b * NP * NP;
+        T *S = lv.S + (size_t)b * NP * NP;
+        const double *Hc = lv.Hc + (size_t)b * (NP / 2) * 4;
+        const double *Y = lv.Y + (size_t)b * NP;
+        const double rm = (double)KR;
+        const int tid = threadIdx.x;
+        const int r0 = LB * I - 1, c0 = LB * J - 1; // global index of halo row / column 0
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        // ---- stage the block: 16-byte loads of the 64 aligned columns (32 lanes per row, 8 rows per pass), then the two halo columns
+        {
+                const int q = tid & 31, rr = tid >> 5;
+#pragma unroll
+                for (int ps = 0; ps < (HB + 7) / 8; ++ps)
+                {
+                        const int r = 8 * ps + rr, gr = r0 + r;
+                        if (r < HB)
+                        {
+                                d2 v = {0.0, 0.0};
+                                if (gr >= 0 && gr < NP)
+                                        v = *reinterpret_cast<const d2 *>(P + (size_t)gr * NP + LB * J + 2 * q);
+                                Pt[r][1 + 2 * q] = v[0], Pt[r][2 + 2 * q] = v[1];
+                        }
+                }
+                if (tid < 2 * HB)
+                {
+                        const int r = tid >> 1, hc = (tid & 1) ? HB - 1 : 0;
+                        const int gr = r0 + r, gc = c0 + hc;
+                        Pt[r][hc] = (gr >= 0 && gr < NP && gc >= 0 && gc < NP) ? P[(size_t)gr * NP + gc] : 0.0;
+                }
+        }
+        if (tid < HB)
+        {
+                const int gr = r0 + tid, gc = c0 + tid;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                {
+                        tI[tid][k] = (gr >= 0 && gr < NP) ? P[(size_t)gr * NP + k] : 0.0;
+                        P3[k][tid] = (gc >= 0 && gc < NP) ? P[(size_t)k * NP + gc] : 0.0;
+                }
+                // H coefficients of row gr (the rows of I and their partners)
+                double u = 0.0, v = 0.0;
+                if (gr >= 3 && gr < n)
+                {
+                        const double *h = Hc + 4 * ((gr - 3) >> 1);
+                        u = (gr & 1) ? h[0] : h[2], v = (gr & 1) ? h[1] : h[3];
+                }
+                cI[tid][0] = u, cI[tid][1] = v;
+        }
+        else if (tid >= 128 && tid < 128 + LB)
+        {
+                const int c = tid - 128, gc = LB * J + c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                        tJ[c][k] = P[(size_t)gc * NP + k];
+                double u = 0.0, v = 0.0;
+                if (gc >= 3 && gc < n)
+                {
+                        const double *h = Hc + 4 * ((gc - 3) >> 1);
+                        u = (gc & 1) ? h[0] : h[2], v = (gc & 1) ? h[1] : h[3];
+                }
+                cJ[c][0] = u, cJ[c][1] = v;
+        }
+        else if (tid >= 192 && tid < 201)
+                P33[(tid - 192) / 3][(tid - 192) % 3] = P[(size_t)((tid - 192) / 3) * NP + (tid - 192) % 3];
+        __syncthreads();
+        // G(a, c) of ekf.cpp:301 for a landmark column c (3 <= c < n) from the pose entries t0, t1, t2 of row a and the row's entries at the pair of c
+        auto gcol = [](bool even, double u, double v, double t0, double t1, double t2, double p_odd, double p_even) -> double {
+                return even ? u * t0 + v * t1 - t2 - u * p_odd - v * p_even : u * t0 + v * t1 - u * p_odd - v * p_even;
+        };
+        const int c = tid & (LB - 1), rq = tid >> 6; // this thread's column of the block, its row inside a pass of four
+        const int gc = LB * J + c;
+        const bool ceven = !(gc & 1);
+        const int co = ceven ? c : c + 1; // halo index of the odd member of column gc's pair (the even one: co + 1)
+        const double uJ = cJ[c][0], vJ = cJ[c][1];
+        // ---- the pose rows of G over the columns of J (binary64; for S)
+        if (rq < 3)
+        {
+                const int m = rq;
+                G3[m][c] = gc >= n ? 0.0 : gc < 3 ? P33[m][gc] : gcol(ceven, uJ, vJ, P33[m][0], P33[m][1], P33[m][2], P3[m][co], P3[m][co + 1]);
+        }
+        __syncthreads();
+        // G of halo row index r (global row r0 + r) at this thread's column, binary64
+        auto g_at = [&](int r) -> double {
+                const int ga = r0 + r;
+                if (ga < 0 || ga > n || gc >= n)
+                        return 0.0; // padding (rows beyond n, columns from n on)
+                if (ga == n)
+                        return Y[gc]; // row n carries Y^T through the solve
+                if (gc < 3)
+                        return Pt[r][c + 1];
+                return gcol(ceven, uJ, vJ, tI[r][0], tI[r][1], tI[r][2], Pt[r][co], Pt[r][co + 1]);
+        };
+        const double g30 = G3[0][c], g31 = G3[1][c], g32 = G3[2][c];
+        // ---- G(I, J) and S(I, J) = H(I, :) G(:, J) + R: entry (r, c) with the G entry of the other row of r's pair
+#pragma unroll 4
+        for (int ps = 0; ps < LB / 4; ++ps)
+        {
+                const int r = 4 * ps + rq, gr = LB * I + r; // block row r = halo row r + 1
+                const double g = g_at(r + 1);
+                G[(size_t)gr * NP + gc] = (T)g;
+                double sv;
+                if (gr >= n)
+                        sv = (gr == gc) ? 1.0 : 0.0; // padding rows: identity
+                else if (gc >= n)
+                        sv = 0.0;
+                else if (gr < 3)
+                        sv = g + (gr == gc ? rm : 0.0);
+                else
+                {
+                        const bool even = !(gr & 1);                    // the bearing row of its landmark
+                        const double gp = g_at(even ? r : r + 2);       // the other row of the pair: gr - 1 / gr + 1
+                        const double go_ = even ? gp : g, ge_ = even ? g : gp;
+                        const double ha = cI[r + 1][0], hb = cI[r + 1][1];
+                        double v = ha * g30 + hb * g31;
+                        if (even)
+                                v -= g32;
+                        sv = v - ha * go_ - hb * ge_;
+                        if (gr == gc)
+                                sv += rm;
+                }
+                S[(size_t)gr * NP + gc] = (T)sv;
+        }
+        // ---- G(J, I): row cr of J, column a of I, from the block read transposed
+        if (I != J)
+        {
+                const int a = c, gcolx = LB * I + a; // this thread's output column (a landmark column: gcolx >= 64)
+                const bool even = !(gcolx & 1);
+                const int ao = even ? a : a + 1; // halo ROW index of the odd member of column gcolx's pair
+                const double uI = cI[a + 1][0], vI = cI[a + 1][1];
+#pragma unroll 4
+                for (int ps = 0; ps < LB / 4; ++ps)
+                {
+                        const int cr = 4 * ps + rq, grow = LB * J + cr;
+                        double g;
+                        if (grow > n || gcolx >= n)
+                                g = 0.0;
+                        else if (grow == n)
+                                g = Y[gcolx];
+                        else
+                                g = gcol(even, uI, vI, tJ[cr][0], tJ[cr][1], tJ[cr][2], Pt[ao][cr + 1], Pt[ao + 1][cr + 1]);
+                        G[(size_t)grow * NP + gcolx] = (T)g;
+                }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // (the diagonal blocks: large_potrf_inv_tiles in ekf_large_chol.h)
 
 /// virtual stacked matrix M = [S; G] (2*na rows): row pointer of virtual row vr

@@ -359,7 +359,9 @@ struct Rows
 /// L(nbk, j) = the X(:, j) this very sweep has just stored as planes, so every store is drained and the block pipeline restarted in front of them --
 /// and the sweep returns  c = S(nbk, nbk) - sum_j X(:, j) X(:, j)^T  (this wave's 16 rows: c[t][r] = column 16 t + 4 lg + r of row li) for the
 /// caller to factor.  `lds`: four block buffers; `gl`: this wave's 16 x 64 floats for the slices of the rows.
-template <int STAMP, bool CHOL>
+/// F32OUT (CHOL only): also store the solved columns in binary32 (the L of large_trsm_pipe and of the diagnostics); the default chain reads L through its
+/// planes only, and the Cholesky is HBM-bound: 2.1 MB of stores per filter less.
+template <int STAMP, bool CHOL, bool F32OUT = true>
 __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsigned short (*lds)[BLK], float *gl, const Planes &pl, int b, int nbk, int nb_rows, int NP,
                                         const Rows &rows, int tid)
 {
@@ -401,7 +403,8 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
         if constexpr (STAMP)
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pp.tlast)::"memory");
         const int klast = CHOL ? nbk : nbk - 1;
-        constexpr int NST = CHOL ? 10 : 4; // vector-memory stores of a closing block per wave (V: 4; the planes of L: 6)
+        static_assert(CHOL || F32OUT, "V is stored in binary32");
+        constexpr int NST = (F32OUT ? 4 : 0) + (CHOL ? 6 : 0); // vector-memory stores of a closing block per wave (binary32: 4; the planes of L: 6)
 #pragma unroll 1
         for (int k = 0; k <= klast; ++k)
         {
@@ -484,9 +487,12 @@ __device__ __forceinline__ void sweep16(f4 (&cdiag)[4], Regs &R, Pipe &pp, unsig
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                         x[t] = tile4(R.e, t);
+                if constexpr (F32OUT)
+                {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                        *reinterpret_cast<f4 *>(rows.out + LB * k + 16 * t) = x[t];
+                        for (int t = 0; t < 4; ++t)
+                                *reinterpret_cast<f4 *>(rows.out + LB * k + 16 * t) = x[t];
+                }
                 if constexpr (CHOL)
                 {
                         // the planes of L(nbk, k): row tiles 2 u and 2 u + 1 of a lane are eight consecutive positions of a permuted plane row
@@ -570,7 +576,8 @@ __global__ __launch_bounds__(256, 1) void large_trsm_bf16(DevView d, LargeView<f
 /// row a sweep16<CHOL> over the planes of the block rows above it -- which this kernel writes as it goes (binary32 L and Linv are written too) --
 /// closed by the 64x64 factorisation of the diagonal block in binary64 tiles.  grid (B), 256 threads.  Status bit 4 (ASLAM_ST_NOT_PD) on a
 /// non-positive pivot.
-template <int NBMAX>
+/// F32OUT = false (the default chain, whose TRSM streams the planes): the off-diagonal blocks of L are not stored in binary32 at all.
+template <int NBMAX, bool F32OUT = true>
 __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<float> lv, t16::Planes pl, const int *skipped)
 {
         using namespace t16;
@@ -609,8 +616,11 @@ __global__ __launch_bounds__(256, 1) void large_chol_bf16(DevView d, LargeView<f
                 rows.out = Sb + (size_t)(LB * I + 16 * wave + li) * NP + 4 * lg;
                 rows.vq = (unsigned)(((LB * I + 16 * wave + li) * NP + 8 * lg) * 2);
                 f4 c[4];
-                asm volatile("; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4 buffer_store_dwordx4=6" ::: "memory"); // (tools/check_vmcnt_protocol.py)
-                sweep16<0, true>(c, R, pp, lds, gl[wv], pl, b, I, nb, NP, rows, tid);
+                if constexpr (F32OUT)
+                        asm volatile("; ASLAM_STRIP_LIVE_BEGIN vmem: global_store_dwordx4=4 buffer_store_dwordx4=6" ::: "memory"); // (tools/check_vmcnt_protocol.py)
+                else
+                        asm volatile("; ASLAM_STRIP_LIVE_BEGIN vmem: buffer_store_dwordx4=6" ::: "memory");
+                sweep16<0, true, F32OUT>(c, R, pp, lds, gl[wv], pl, b, I, nb, NP, rows, tid);
                 asm volatile("; ASLAM_STRIP_LIVE_END" ::: "memory");
                 // every DMA piece still in flight targets the buffers the tiles are about to take
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");

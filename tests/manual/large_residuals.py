@@ -24,6 +24,7 @@ sys.path.insert(0, "tests")
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 os.environ["ASLAM_CHOL_RESIDENT"] = sys.argv[3] if len(sys.argv) > 3 else "0"
+os.environ["ASLAM_KEEP_L32"] = "1"  # large_chol_bf16 stores the off-diagonal blocks of L in binary32 only on request (this script reads L back)
 
 import torch  # noqa: E402,F401
 from awesomeslam_amd import trace as tg  # noqa: E402

@@ -335,3 +335,35 @@ def test_fp32_drift_over_2000_callbacks(built, monkeypatch):
     assert rel_err(X32, X64) < 1e-8
     assert rel_err(P32, P64) < REL_TOL and cov_err(P32, P64) < F32_DRIFT_TOL
     assert np.abs(P32 - P32.T).max() <= 1e-18, "the fp32 update mirrors the lower triangle: P stays symmetric (up to the two predict roundings of the pose block)"
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32-resident"])
+def test_tiled_GS_is_bit_identical(dtype, built, monkeypatch):
+    """G = P H^T and S = H G + R from the lower block triangle of P alone (large_build_GS_tiles, round 4: 4.4 instead of 8.4 MB of P read per filter)
+    against the row-pair kernel that reads all of P (large_build_GS, ASLAM_GS_TILES=0): the same expressions in the same order, so every later
+    number -- dimensions, X, the whole covariance, the pose stream -- must agree BIT FOR BIT over a replay with growth in stages (blocks that are
+    part padding, the Y^T row, pairs that straddle 64-blocks: 100 landmarks = n 203 crosses three block boundaries)."""
+    import torch
+    from awesomeslam_amd.core import Core, F32, F64
+
+    dt = chol_mode(dtype, monkeypatch)
+    L, T, B = 100, 70, 2
+    tr = tg.make_traces(L, T, B=B, seed=66)
+    out = {}
+    for tiles in ("0", "1"):
+        monkeypatch.setenv("ASLAM_GS_TILES", tiles)
+        core = Core("ekf", tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=2048, dtype=F32 if dt == "f32" else F64)
+        core.set_trace(tr)
+        poses = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+        dims = torch.zeros((B, T), dtype=torch.int32, device="cuda")
+        core.replay(0, T, poses.data_ptr(), dims.data_ptr())
+        torch.cuda.synchronize()
+        out[tiles] = (poses.cpu().numpy(), dims.cpu().numpy(), [core.state(b) for b in range(B)], [core.status(b) for b in range(B)])
+        core.close()
+    monkeypatch.delenv("ASLAM_GS_TILES")
+    (p0, d0, s0, st0), (p1, d1, s1, st1) = out["0"], out["1"]
+    assert st0 == st1 == [0] * B and np.array_equal(d0, d1) and d1[0, -1] == tg.full_dim(L)
+    assert np.array_equal(p0, p1), f"pose streams differ: max {np.abs(p0 - p1).max():.3e}"
+    for b in range(B):
+        for a, c, name in zip(s0[b], s1[b], "XZP"):
+            assert np.array_equal(a, c), f"{name} of filter {b} differs: max {np.abs(a - c).max():.3e}"
