@@ -1422,29 +1422,6 @@ __global__ __launch_bounds__(256, 3) void large_syrk_bf16x3(DevView d, LargeView
         }
 }
 
-/// Sum of x over the 64 lanes of a wave, valid in lane 63, by DPP moves only (quad permutes, row mirrors, row broadcasts: VALU instructions).
-/// __shfl_xor is a ds_bpermute -- an LDS crossbar instruction: the five binary64 sums per row of large_x_update<.., SLIM> were 60 of them per
-/// wave and made the kernel LDS-bound (393 us per 256 filters against 217 for the one sum of round 2; profiles/r03_experiments.md).
-__device__ __forceinline__ double wave_sum_dpp(double x)
-{
-        auto step = [](double v, auto ctrl, auto rmask) {
-                constexpr int C = decltype(ctrl)::value, RM = decltype(rmask)::value;
-                const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-                const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, RM, 0xf, false);
-                const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, RM, 0xf, false);
-                const double o = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-                return v + o; // lanes outside the row mask add the 0 of `old`
-        };
-        using std::integral_constant;
-        x = step(x, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});  // quad_perm [1,0,3,2]
-        x = step(x, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});  // quad_perm [2,3,0,1]
-        x = step(x, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}); // row_half_mirror
-        x = step(x, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}); // row_mirror: every lane holds its row's sum
-        x = step(x, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}); // row_bcast:15 into rows 1, 3
-        x = step(x, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2, 3: lane 63 holds the wave's sum
-        return x;
-}
-
 /// X <- X + V q with q = row n of G = (L^-1 Y)^T; one wave per state row.  grid (ceil(NP/4), B), 256 threads.  In replay
 /// mode also writes the pose of this callback.
 ///

@@ -60,7 +60,9 @@ enum
 {
         GEMM_STORE = 0,    // C = A diag(w) B^T            (HBM, full matrix)
         GEMM_SUBTRACT = 1, // C -= A diag(w) B^T           (HBM, full matrix)
-        GEMM_TILES = 2     // lower tiles of A diag(w) B^T + diag_add on the true diagonal -> LDS tile storage
+        GEMM_TILES = 2,    // lower tiles of A diag(w) B^T + diag_add on the true diagonal -> LDS tile storage
+        GEMM_SUBTRACT_SYM = 3 // C -= A diag(w) A^T for a symmetric C: the lower tiles are computed (45 instead of 81 at NT = 9) and their new values stored
+                              // into the upper triangle as well -- the (i, j) and (j, i) sums of the full product are the same MFMA chains, bit for bit
 };
 
 /// C (op)= A diag(w) B^T over k = 0 .. 16*nks-1 (SKIP_K0: without the k = 0 term).  A, B: row-major HBM with row stride ld (>= 16*nks), rows
@@ -73,12 +75,12 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
 {
         typedef UkfLayout<NT> UL;
         constexpr int NP = UL::NP, LD = UL::SLAB_LD, SLAB = UL::SLAB;
-        constexpr int TPW = (MODE == GEMM_TILES) ? (NT * (NT + 1) / 2 + SMALL_WAVES - 1) / SMALL_WAVES
-                                                 : (NT * NT + SMALL_WAVES - 1) / SMALL_WAVES;
+        constexpr bool LOWER = (MODE == GEMM_TILES || MODE == GEMM_SUBTRACT_SYM);
+        constexpr int TPW = LOWER ? (NT * (NT + 1) / 2 + SMALL_WAVES - 1) / SMALL_WAVES : (NT * NT + SMALL_WAVES - 1) / SMALL_WAVES;
         const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
         const bool same = (A == B);
         const int rows = 16 * nt;
-        const int ntiles = (MODE == GEMM_TILES) ? nt * (nt + 1) / 2 : nt * nt;
+        const int ntiles = LOWER ? nt * (nt + 1) / 2 : nt * nt;
 
         // my output tiles
         int tib[TPW], tjb[TPW];
@@ -90,7 +92,7 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                 int ib = 0, jb = 0;
                 if (tl < ntiles)
                 {
-                        if (MODE == GEMM_TILES)
+                        if (LOWER)
                         {
                                 ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
                                 while ((ib + 1) * (ib + 2) / 2 <= tl)
@@ -202,8 +204,95 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                                 }
                                 else if (MODE == GEMM_STORE)
                                         Cg[(size_t)i * NP + j] = acc[q][r];
-                                else // GEMM_SUBTRACT, with an optional rank-one term gscale * g g^T (g: LDS, zero beyond the true dimension)
+                                else if (MODE == GEMM_SUBTRACT) // with an optional rank-one term gscale * g g^T (g: LDS, zero beyond the true dimension)
                                         Cg[(size_t)i * NP + j] -= gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r];
+                                else // GEMM_SUBTRACT_SYM
+                                {
+                                        const double nv = Cg[(size_t)i * NP + j] - (gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r]);
+                                        Cg[(size_t)i * NP + j] = nv;
+                                        if (ib != jb)
+                                                Cg[(size_t)j * NP + i] = nv;
+                                }
+                        }
+                }
+        }
+        __syncthreads();
+}
+
+/// Landmark rows of the cross covariance (round 4):  Tc(a, b) = sum_{c <= a} L(a, c) E(c, b) + delta_a s(b),  a >= 3  (rows 0 .. 2 are written by the
+/// sigma-point phase and left alone).  A operand = the lower tiles of L = chol(P) where they lie in LDS (`Lt`; the diagonal tiles are masked to their
+/// lower triangle), B operand = E^T (`ETg`: HBM / L2, row b = measurement, row stride NP), staged slab by slab (16 columns of E^T for all rows) in
+/// `slab` -- the area of the inverted diagonal tiles, dead between the two factorisations; single-buffered: L keeps the tile region.  Both factors are
+/// (block) triangular -- L(a, c) = 0 for c > a, E(c, b) = 0 for c > b + 2 -- so output tile (ib, jb) takes the slabs ks <= min(ib, jb + 1) only.
+/// delta = X - Xbar, s = sum_i w_i dz_i (LDS vectors).  All threads take part; ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void gemm_l_et(const double *Lt, const double *ETg, int nt, int n_true, const double *sX, const double *sXbar, const double *sS,
+                                          double *Tcg, double *slab, int tid)
+{
+        typedef UkfLayout<NT> UL;
+        constexpr int NP = UL::NP, LD = UL::SLAB_LD;
+        constexpr int TPW = (NT * NT + SMALL_WAVES - 1) / SMALL_WAVES;
+        static_assert(UL::SLAB <= NT * TSZ, "the slab of E^T takes the place of the inverted diagonal tiles");
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        const int ntiles = nt * nt, rows = 16 * nt;
+        int tib[TPW], tjb[TPW];
+        d4 acc[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+        {
+                const int tl = wave + q * SMALL_WAVES;
+                tib[q] = tl < ntiles ? tl / nt : 0;
+                tjb[q] = tl < ntiles ? tl - tib[q] * nt : 0;
+                acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        const int npairs = rows * 8;
+        __syncthreads(); // whatever lived in the slab area before is dead from here on
+        for (int ks = 0; ks < nt; ++ks)
+        {
+                // stage columns 16 ks .. 16 ks + 15 of E^T for all rows: element pairs, one 16-byte load per pair
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                        const int pi = tid + u * SMALL_WG;
+                        if (pi < npairs)
+                        {
+                                const int r = pi >> 3, c2 = (pi & 7) * 2;
+                                const double2 v = *reinterpret_cast<const double2 *>(ETg + (size_t)r * NP + 16 * ks + c2);
+                                slab[r * LD + c2] = v.x;
+                                slab[r * LD + c2 + 1] = v.y;
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                {
+                        if (wave + q * SMALL_WAVES < ntiles && ks <= min(tib[q], tjb[q] + 1))
+                        {
+                                const double *ar = Lt + tile_index(tib[q], ks) * TSZ + li * TLD + lg; // L(16 ib + li, 16 ks + lg + 4 s)
+                                const double *br = slab + (16 * tjb[q] + li) * LD + lg;             // E^T(16 jb + li, 16 ks + lg + 4 s)
+                                const bool diag = (ks == tib[q]);
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                {
+                                        const double a = (diag && lg + 4 * s > li) ? 0.0 : ar[4 * s];
+                                        acc[q] = mfma_f64(a, br[4 * s], acc[q]);
+                                }
+                        }
+                }
+                __syncthreads();
+        }
+        // write out: lane l, register r of a tile = element (row (l >> 4) + 4 r, column l & 15)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+        {
+                if (wave + q * SMALL_WAVES < ntiles)
+                {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                                const int i = 16 * tib[q] + lg + 4 * r, j = 16 * tjb[q] + li;
+                                if (i >= 3)
+                                        Tcg[(size_t)i * NP + j] = (i < n_true && j < n_true) ? fma(sX[i] - sXbar[i], sS[j], acc[q][r]) : 0.0;
                         }
                 }
         }
@@ -391,18 +480,58 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 }
                 __syncthreads();
 
+                // ---- the few sigma points whose POSE differs from the centre's: L is lower triangular, so only the columns c < 3 of L move the pose, and the
+                // acceleration-noise column c = n accelerates it (column n + 1, the yaw acceleration, does not enter f: common.h:64-73 adds az, not the noise);
+                // every other sigma point carries the centre's pose through f bit for bit.  So for the pose entries d_i(k) = XsigPred_i(k) - Xbar(k):
+                //   SWD(k)    = sum_i w_i d_i(k)                              (all 2 N + 5 points)
+                //   EP(k, c)  = w_1 (d_{c+}(k) - d_{c-}(k)),  c < 3           (what the +- pair of column c leaves of the pose entry k)
+                double *const sS = sVv, *const sSWD = sGv, *const sEP = sGv + 4; // (sVv, sGv: free until the solve)
+                auto dpose = [&](int k, int i) -> double {
+                        const double v = sXP[k * UL::MP + i] - sXbar[k];
+                        return k == 2 ? (double)normalizeAngle((float)v) : v;
+                };
+                {
+                        const int lane = tid & 63;
+                        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                        if (wave < 3)
+                        {
+                                double a = 0.0;
+                                for (int i = lane; i < m; i += 64)
+                                        a = fma(sW[i], dpose(wave, i), a);
+                                a = wave_sum_dpp(a);
+                                if (lane == 63)
+                                        sSWD[wave] = a;
+                        }
+                        else if (wave == 3 && lane < 9)
+                        {
+                                const int k = lane / 3, c = lane - 3 * k;
+                                sEP[lane] = w_i * (dpose(k, c + 1) - dpose(k, c + n + 3));
+                        }
+                }
+                __syncthreads();
+
                 ASLAM_STAMP(2);
-                // ---- D = XsigPred - X (ukf.cpp:311-312), Zsig = h(XsigPred) (ukf.cpp:322-326, common.h:78-90), Zpred (ukf.cpp:329-339),
-                // DZ = Zsig - Zpred (ukf.cpp:346-351), Zdiff (ukf.cpp:381-386) and the pose rows of P (ukf.cpp:307-319), one wave per row
-                // pair.  A sigma point moves landmark j (or the pose it is seen from) only if its column c of L is a pose column,
-                // the acceleration-noise column (c = n) or c <= 4 + 2 j (L is lower triangular); every other sigma point reproduces
-                // the centre point's reading bit for bit.  The wave evaluates h on the dense list of affected points only, keeps the
-                // readings in registers, reduces Zpred across lanes and writes each DZ entry once.
+                // ---- Zsig = h(XsigPred) (ukf.cpp:322-326, common.h:78-90), Zpred (ukf.cpp:329-339), DZ = Zsig - Zpred (ukf.cpp:346-351), Zdiff
+                // (ukf.cpp:381-386), the pose rows of P (ukf.cpp:307-319) and what the cross covariance Tc (ukf.cpp:360-375) needs, one wave per measurement
+                // row pair.  A sigma point moves landmark j (or the pose it is seen from) only if its column c of L is a pose column, the acceleration-
+                // noise column (c = n) or c <= 4 + 2 j (L is lower triangular); every other sigma point reproduces the centre point's reading bit for
+                // bit.  The wave evaluates h on the dense list of affected COLUMNS (a lane takes both signs of its column), keeps the readings in
+                // registers, reduces Zpred across lanes and writes each DZ entry once.
+                //
+                // Round 4: the state differences D = XsigPred - Xbar are no longer materialised (350 KB per filter and callback written and read back).  For a
+                // landmark entry a the sigma points are affine, d_i(a) = delta_a +- w L(a, c_i) with delta_a = X(a) - Xbar(a), so
+                //     Tc(a, b)  = sum_i w_i d_i(a) dz_i(b)  =  sum_{c < n} L(a, c) E(c, b)  +  delta_a s(b)
+                //     E(c, b)   = w_1 w (dz_{c+}(b) - dz_{c-}(b)),          s(b) = sum_i w_i dz_i(b)
+                // -- a product over the n columns of L (in LDS, lower triangular) instead of 2 N + 5 sigma points, with E zero wherever column c does not
+                // move measurement b (c > 5 + 2 j): the waves write E^T row by row next to DZ, and s; the three pose rows of Tc are
+                //     Tc(k, b)  = d_0(k) s(b) + sum_{c in {0, 1, 2, n}, +-} w_1 (d_i(k) - d_0(k)) dz_i(b)
+                // and the pose columns of P:  P(a, k) = w sum_{c < 3} L(a, c) EP(k, c) + delta_a SWD(k).
                 {
                         const int lane = tid & 63;
                         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
                         constexpr int NWAVE = SMALL_WG / 64;
-                        constexpr int DCH = (2 * 16 * NT + 3 + 63) / 64; // chunks of the dense list (at most 2 n + 3 entries)
+                        constexpr int DCH = (16 * NT + 2 + 63) / 64; // chunks of the dense list of columns (the centre, columns 0 .. cmax, column n)
+                        double *ETg = Dg; // E^T [16 nt][NP] takes the place of D
                         for (int k = 16 * nt + tid; k < NP; k += SMALL_WG)
                         {
                                 sY[k] = 0.0;
@@ -414,134 +543,137 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                         v += __shfl_xor(v, o);
                                 return v;
                         };
+                        const double d00 = dpose(0, 0), d01 = dpose(1, 0), d02 = dpose(2, 0); // the centre point's pose differences
+                        const double ew = w_i * wsp;
                         for (int r = wave; r < 3 + nl + (16 * nt - n); r += NWAVE)
                         {
                                 if (r < 3)
                                 {
-                                        // pose row k: D from the propagated poses, Zsig passes the pose through, 3 x 3 block of P
+                                        // pose measurement row k: Zsig passes the pose through; 3 x 3 blocks of P and of Tc, s(k), row k of E^T
                                         const int k = r;
                                         const double zp = (k == 2) ? (double)normalizeAngle((float)sXbar[2]) : sXbar[k];
-                                        double acc[3] = {0.0, 0.0, 0.0};
+                                        double acc[3] = {0.0, 0.0, 0.0}, tcc[3] = {0.0, 0.0, 0.0}, sacc = 0.0;
                                         for (int i = lane; i < 16 * mt; i += 64)
                                         {
                                                 double dv[3] = {0.0, 0.0, 0.0}, z = 0.0;
                                                 if (i < m)
                                                 {
-                                                        dv[0] = sXP[i] - sXbar[0];
-                                                        dv[1] = sXP[UL::MP + i] - sXbar[1];
-                                                        dv[2] = (double)normalizeAngle((float)(sXP[2 * UL::MP + i] - sXbar[2]));
+                                                        dv[0] = dpose(0, i);
+                                                        dv[1] = dpose(1, i);
+                                                        dv[2] = dpose(2, i);
                                                         z = sXP[k * UL::MP + i] - zp;
                                                         if (k == 2)
                                                                 z = (double)normalizeAngle((float)z);
                                                 }
                                                 const double dk = (k == 0) ? dv[0] : (k == 1) ? dv[1] : dv[2];
-                                                Dg[(size_t)k * MP + i] = dk;
                                                 DZg[(size_t)k * MP + i] = z;
                                                 const double wd = sW[i] * dk;
+                                                sacc = fma(sW[i], z, sacc);
 #pragma unroll
                                                 for (int a = 0; a < 3; ++a)
+                                                {
                                                         acc[a] = fma(wd, dv[a], acc[a]);
+                                                        tcc[a] = fma(sW[i] * dv[a], z, tcc[a]); // (w d_a) dz_k, ukf.cpp:374
+                                                }
                                         }
 #pragma unroll
                                         for (int a = 0; a < 3; ++a)
-                                                acc[a] = wave_sum(acc[a]);
-                                        if (lane == 0)
+                                        {
+                                                acc[a] = wave_sum_dpp(acc[a]);
+                                                tcc[a] = wave_sum_dpp(tcc[a]);
+                                        }
+                                        sacc = wave_sum_dpp(sacc);
+                                        // row k of E^T: only the pose columns (and column n, which no landmark row of L reaches) move a pose reading
+                                        for (int c = lane; c < 16 * nt; c += 64)
+                                        {
+                                                double e = 0.0;
+                                                if (c < n)
+                                                {
+                                                        double zp_ = sXP[k * UL::MP + c + 1] - zp, zm_ = sXP[k * UL::MP + c + n + 3] - zp;
+                                                        if (k == 2)
+                                                                zp_ = (double)normalizeAngle((float)zp_), zm_ = (double)normalizeAngle((float)zm_);
+                                                        e = ew * (zp_ - zm_);
+                                                }
+                                                ETg[(size_t)k * NP + c] = e;
+                                        }
+                                        if (lane == 63)
                                         {
 #pragma unroll
                                                 for (int a = 0; a < 3; ++a)
+                                                {
                                                         Pg[(size_t)k * NP + a] = acc[a] + ((a == k) ? q_proc : 0.0);
+                                                        Tcg[(size_t)a * NP + k] = tcc[a];
+                                                }
                                                 double zd = sZ[k] - zp;
                                                 if (k == 2)
                                                         zd = (double)normalizeAngle((float)zd);
                                                 sY[k] = zd;
                                                 sZpred[k] = zp;
+                                                sS[k] = sacc;
                                         }
                                 }
                                 else if (r < 3 + nl)
                                 {
                                         const int j = r - 3, ka = 3 + 2 * j, kb = 4 + 2 * j;
-                                        const double xba = sXbar[ka], xbb = sXbar[kb];
-                                        // rows ka, kb of D and their products with the three pose rows
-                                        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                                        for (int i = lane; i < 16 * mt; i += 64)
-                                        {
-                                                double da = 0.0, db = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0;
-                                                if (i < m)
-                                                {
-                                                        int c;
-                                                        double sg;
-                                                        col_of(i, c, sg);
-                                                        da = xsig(ka, c, sg) - xba;
-                                                        db = xsig(kb, c, sg) - xbb;
-                                                        p0 = sXP[i] - sXbar[0];
-                                                        p1 = sXP[UL::MP + i] - sXbar[1];
-                                                        p2 = (double)normalizeAngle((float)(sXP[2 * UL::MP + i] - sXbar[2]));
-                                                }
-                                                Dg[(size_t)ka * MP + i] = da;
-                                                Dg[(size_t)kb * MP + i] = db;
-                                                const double wa = sW[i] * da, wb = sW[i] * db;
-                                                acc[0] = fma(wa, p0, acc[0]);
-                                                acc[1] = fma(wa, p1, acc[1]);
-                                                acc[2] = fma(wa, p2, acc[2]);
-                                                acc[3] = fma(wb, p0, acc[3]);
-                                                acc[4] = fma(wb, p1, acc[4]);
-                                                acc[5] = fma(wb, p2, acc[5]);
-                                        }
-#pragma unroll
-                                        for (int a = 0; a < 6; ++a)
-                                                acc[a] = wave_sum(acc[a]);
+                                        // the pose columns of P for rows ka, kb (and their mirror image)
                                         if (lane < 6)
                                         {
                                                 const int a = lane % 3, kk = (lane < 3) ? ka : kb;
-                                                double v = acc[0];
+                                                double v = 0.0;
 #pragma unroll
-                                                for (int q = 1; q < 6; ++q)
-                                                        v = (lane == q) ? acc[q] : v;
+                                                for (int c = 0; c < 3; ++c)
+                                                        v = fma(Lkc(kk, c), sEP[3 * a + c], v);
+                                                v = fma(wsp, v, (sX[kk] - sXbar[kk]) * sSWD[a]);
                                                 Pg[(size_t)a * NP + kk] = v;
                                                 Pg[(size_t)kk * NP + a] = v; // mirror (the reference's two roundings differ in the last bit only)
                                         }
-                                        // dense list of affected sigma points: a = 0 is the centre, then '+' columns 0..cmax and n, then '-'
+                                        // dense list of affected columns: entry 0 is the centre point, entry 1 + e column c = e (e <= cmax) or n (e = cmax + 1), both signs
                                         const int cmax = min(4 + 2 * j, n - 1);
                                         const int npl = cmax + 2;
-                                        const int na = 1 + 2 * npl;
-                                        double zr[DCH], zb[DCH];
-                                        int si[DCH];
+                                        const int nE = 1 + npl;        // list entries
+                                        const int na = 1 + 2 * npl;    // affected sigma points
+                                        double zrp[DCH], zbp[DCH], zrm[DCH], zbm[DCH];
+                                        int cc[DCH];
                                         double sr = 0.0, sb = 0.0;
+                                        auto hread = [&](int c, double sg, int i, double &zr_, double &zb_) {
+                                                const double lx = xsig(ka, c, sg), ly = xsig(kb, c, sg);
+                                                const double ddx = lx - sXP[i], ddy = ly - sXP[UL::MP + i];
+                                                zr_ = sqrt(ddx * ddx + ddy * ddy);
+                                                zb_ = atan2(ddy, ddx) - sXP[2 * UL::MP + i];
+                                        };
 #pragma unroll
                                         for (int q = 0; q < DCH; ++q)
                                         {
                                                 const int a = lane + 64 * q;
-                                                zr[q] = 0.0;
-                                                zb[q] = 0.0;
-                                                si[q] = -1;
-                                                if (64 * q < na && a < na) // first test is wave-uniform: whole chunks are skipped
+                                                zrp[q] = zbp[q] = zrm[q] = zbm[q] = 0.0;
+                                                cc[q] = -2; // no entry
+                                                if (64 * q < nE && a < nE) // first test is wave-uniform: whole chunks are skipped
                                                 {
-                                                        int c = -1, i = 0;
-                                                        double sg = 0.0;
-                                                        if (a > 0)
+                                                        if (a == 0)
                                                         {
-                                                                int e = a - 1;
-                                                                const bool neg = e >= npl;
-                                                                if (neg)
-                                                                        e -= npl;
-                                                                c = (e <= cmax) ? e : n;
-                                                                sg = neg ? -1.0 : 1.0;
-                                                                i = neg ? c + n + 3 : c + 1;
+                                                                cc[q] = -1;
+                                                                hread(-1, 0.0, 0, zrp[q], zbp[q]);
+                                                                sr = fma(sW[0], zrp[q], sr);
+                                                                sb = fma(sW[0], zbp[q], sb);
                                                         }
-                                                        const double lx = xsig(ka, c, sg), ly = xsig(kb, c, sg);
-                                                        const double ddx = lx - sXP[i], ddy = ly - sXP[UL::MP + i];
-                                                        zr[q] = sqrt(ddx * ddx + ddy * ddy);
-                                                        zb[q] = atan2(ddy, ddx) - sXP[2 * UL::MP + i];
-                                                        si[q] = i;
-                                                        sr = fma(sW[i], zr[q], sr);
-                                                        sb = fma(sW[i], zb[q], sb);
+                                                        else
+                                                        {
+                                                                const int e = a - 1, c = (e <= cmax) ? e : n;
+                                                                cc[q] = c;
+                                                                hread(c, 1.0, c + 1, zrp[q], zbp[q]);
+                                                                hread(c, -1.0, c + n + 3, zrm[q], zbm[q]);
+                                                                sr = fma(w_i, zrp[q], sr);
+                                                                sb = fma(w_i, zbp[q], sb);
+                                                                sr = fma(w_i, zrm[q], sr);
+                                                                sb = fma(w_i, zbm[q], sb);
+                                                        }
                                                 }
                                         }
-                                        const double z0r = readfirstlane_f64(zr[0]), z0b = readfirstlane_f64(zb[0]);
+                                        const double z0r = readfirstlane_f64(zrp[0]), z0b = readfirstlane_f64(zbp[0]);
                                         const double wrest = w_i * (double)(m - na); // the unaffected points all carry w_i and the centre reading
                                         const double zpr = fma(wrest, z0r, wave_sum(sr));
                                         const double zpb = (double)normalizeAngle((float)fma(wrest, z0b, wave_sum(sb)));
-                                        // unaffected columns and padding first, then every affected point overwrites nothing: the sets are disjoint
+                                        // unaffected sigma points and padding first (the affected ones are a disjoint set); E^T is zero beyond column cmax
                                         const double ur = z0r - zpr, ub = (double)normalizeAngle((float)(z0b - zpb));
                                         for (int i = lane; i < 16 * mt; i += 64)
                                         {
@@ -555,15 +687,75 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                                         DZg[(size_t)kb * MP + i] = (i < m) ? ub : 0.0;
                                                 }
                                         }
+                                        for (int c = cmax + 1 + lane; c < 16 * nt; c += 64)
+                                        {
+                                                ETg[(size_t)ka * NP + c] = 0.0;
+                                                ETg[(size_t)kb * NP + c] = 0.0;
+                                        }
+                                        // the affected points: DZ, E^T, s and the pose rows of Tc
+                                        double s_r = 0.0, s_b = 0.0, tr[3] = {0.0, 0.0, 0.0}, tb[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                                         for (int q = 0; q < DCH; ++q)
-                                                if (si[q] >= 0)
-                                                {
-                                                        DZg[(size_t)ka * MP + si[q]] = zr[q] - zpr;
-                                                        DZg[(size_t)kb * MP + si[q]] = (double)normalizeAngle((float)(zb[q] - zpb));
-                                                }
-                                        if (lane == 0)
                                         {
+                                                if (cc[q] == -1)
+                                                {
+                                                        const double dr = zrp[q] - zpr, db = (double)normalizeAngle((float)(zbp[q] - zpb));
+                                                        DZg[(size_t)ka * MP] = dr;
+                                                        DZg[(size_t)kb * MP] = db;
+                                                        s_r = fma(sW[0], dr, s_r);
+                                                        s_b = fma(sW[0], db, s_b);
+                                                }
+                                                else if (cc[q] >= 0)
+                                                {
+                                                        const int c = cc[q], ip = c + 1, im = c + n + 3;
+                                                        const double drp = zrp[q] - zpr, drm = zrm[q] - zpr;
+                                                        const double dbp = (double)normalizeAngle((float)(zbp[q] - zpb)), dbm = (double)normalizeAngle((float)(zbm[q] - zpb));
+                                                        DZg[(size_t)ka * MP + ip] = drp;
+                                                        DZg[(size_t)ka * MP + im] = drm;
+                                                        DZg[(size_t)kb * MP + ip] = dbp;
+                                                        DZg[(size_t)kb * MP + im] = dbm;
+                                                        if (c < n)
+                                                        {
+                                                                ETg[(size_t)ka * NP + c] = ew * (drp - drm);
+                                                                ETg[(size_t)kb * NP + c] = ew * (dbp - dbm);
+                                                        }
+                                                        s_r = fma(w_i, drp, s_r);
+                                                        s_r = fma(w_i, drm, s_r);
+                                                        s_b = fma(w_i, dbp, s_b);
+                                                        s_b = fma(w_i, dbm, s_b);
+                                                        if (c < 3 || c == n) // the sigma points whose pose is not the centre's
+                                                        {
+                                                                const double dp[3] = {dpose(0, ip) - d00, dpose(1, ip) - d01, dpose(2, ip) - d02};
+                                                                const double dm[3] = {dpose(0, im) - d00, dpose(1, im) - d01, dpose(2, im) - d02};
+#pragma unroll
+                                                                for (int k = 0; k < 3; ++k)
+                                                                {
+                                                                        tr[k] = fma(w_i * dp[k], drp, tr[k]);
+                                                                        tr[k] = fma(w_i * dm[k], drm, tr[k]);
+                                                                        tb[k] = fma(w_i * dp[k], dbp, tb[k]);
+                                                                        tb[k] = fma(w_i * dm[k], dbm, tb[k]);
+                                                                }
+                                                        }
+                                                }
+                                        }
+                                        s_r = wave_sum_dpp(s_r), s_b = wave_sum_dpp(s_b);
+#pragma unroll
+                                        for (int k = 0; k < 3; ++k)
+                                                tr[k] = wave_sum_dpp(tr[k]), tb[k] = wave_sum_dpp(tb[k]);
+                                        if (lane == 63)
+                                        {
+                                                // the m - na unaffected points read (ur, ub) and carry the centre's pose
+                                                s_r = fma(wrest, ur, s_r);
+                                                s_b = fma(wrest, ub, s_b);
+                                                sS[ka] = s_r;
+                                                sS[kb] = s_b;
+                                                const double d0[3] = {d00, d01, d02};
+#pragma unroll
+                                                for (int k = 0; k < 3; ++k)
+                                                {
+                                                        Tcg[(size_t)k * NP + ka] = fma(d0[k], s_r, tr[k]);
+                                                        Tcg[(size_t)k * NP + kb] = fma(d0[k], s_b, tb[k]);
+                                                }
                                                 sY[ka] = sZ[ka] - zpr;
                                                 sY[kb] = (double)normalizeAngle((float)(sZ[kb] - zpb));
                                                 sZpred[ka] = zpr;
@@ -575,14 +767,14 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                         // padding rows n .. 16 nt - 1
                                         const int k = n + (r - 3 - nl);
                                         for (int i = lane; i < 16 * mt; i += 64)
-                                        {
-                                                Dg[(size_t)k * MP + i] = 0.0;
                                                 DZg[(size_t)k * MP + i] = 0.0;
-                                        }
+                                        for (int c = lane; c < 16 * nt; c += 64)
+                                                ETg[(size_t)k * NP + c] = 0.0;
                                         if (lane == 0)
                                         {
                                                 sY[k] = 0.0;
                                                 sZpred[k] = 0.0;
+                                                sS[k] = 0.0;
                                         }
                                 }
                         }
@@ -608,8 +800,8 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 ASLAM_STAMP(4);
 
                 ASLAM_STAMP(5);
-                // ---- Tc = sum w d dz^T (ukf.cpp:360-375) -> HBM
-                gemm_wabt<NT, GEMM_STORE>(Dg, DZg, MP, mt, sW, nt, Tcg, nullptr, 0.0, n, stage, tid);
+                // ---- the landmark rows of Tc = L E + delta s^T (ukf.cpp:360-375 in the form above) -> HBM; the pose rows are there already
+                gemm_l_et<NT>(Lt, Dg, nt, n, sX, sXbar, sS, Tcg, Dinv, tid); // (E^T lies where D was)
                 // ---- S = sum w dz dz^T + R (ukf.cpp:342-357).  The central weight w_0 = (1-N)/3 is negative, so S can be
                 // indefinite (it is whenever the sigma-point headings straddle +-pi); the reference does not care because it
                 // inverts S by LU (S.inverse(), ukf.cpp:378).  Here: S = S+ - z z^T with S+ = sum_{i>=1} w_i dz_i dz_i^T + R
@@ -666,7 +858,7 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         }
                         ASLAM_STAMP(9);
                         // ---- P = P - K S K^T (ukf.cpp:391) = P - W W^T - g g^T / (1 - q.q)
-                        gemm_wabt<NT, GEMM_SUBTRACT>(Kg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
+                        gemm_wabt<NT, GEMM_SUBTRACT_SYM>(Kg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
                 }
 
                 ASLAM_STAMP(10);
