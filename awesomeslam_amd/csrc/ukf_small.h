@@ -71,7 +71,8 @@ enum
 template <int NT, int MODE, bool SKIP_K0 = false>
 __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int ld, int nks, const double *w, int nt,
                                           double *Cg, double *Ct, double diag_add, int n_true, double *stage, int tid,
-                                          const double *gvec = nullptr, double gscale = 0.0)
+                                          const double *gvec = nullptr, double gscale = 0.0, const double *pdelta = nullptr, double pcll = 0.0,
+                                          double pwsum = 0.0)
 {
         typedef UkfLayout<NT> UL;
         constexpr int NP = UL::NP, LD = UL::SLAB_LD, SLAB = UL::SLAB;
@@ -111,7 +112,6 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                 tjb[q] = jb;
                 acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
         }
-
         // slab loader: element pairs (row, 2 consecutive k) -> one 16-byte load per pair
         const int npairs = rows * 8;
         double2 ra[2], rbv[2];
@@ -208,7 +208,11 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                                         Cg[(size_t)i * NP + j] -= gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r];
                                 else // GEMM_SUBTRACT_SYM
                                 {
-                                        const double nv = Cg[(size_t)i * NP + j] - (gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r]);
+                                        double old = Cg[(size_t)i * NP + j];
+                                        // the UKF's predicted landmark block, folded into this pass (pdelta = X - Xbar): see ukf_small_kernel
+                                        if (pdelta && i >= 3 && j >= 3 && i < n_true && j < n_true)
+                                                old = fma(pcll, old, pwsum * pdelta[i] * pdelta[j]);
+                                        const double nv = old - (gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r]);
                                         Cg[(size_t)i * NP + j] = nv;
                                         if (ib != jb)
                                                 Cg[(size_t)j * NP + i] = nv;
@@ -386,21 +390,27 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
 
                 // ---- L = Paug.llt().matrixL(), ukf.cpp:280: lower tiles of P -> LDS -> tile Cholesky
                 {
+                        // a wave takes whole tiles (the row / column of a tile from its index once per tile, not per element)
                         const int ntl = nt * (nt + 1) / 2;
-                        for (int idx = tid; idx < ntl * 256; idx += SMALL_WG)
+                        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                        for (int tl = wave; tl < ntl; tl += SMALL_WG / 64)
                         {
-                                const int tl = idx >> 8, e = idx & 255;
                                 int ib = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
                                 while ((ib + 1) * (ib + 2) / 2 <= tl)
                                         ++ib;
                                 while (ib * (ib + 1) / 2 > tl)
                                         --ib;
                                 const int jb = tl - ib * (ib + 1) / 2;
-                                const int i = 16 * ib + (e >> 4), j = 16 * jb + (e & 15);
-                                double v = Pg[(size_t)i * NP + j];
-                                if (i == j && i >= n)
-                                        v = 1.0;
-                                Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = v;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                {
+                                        const int e = lane + 64 * q;
+                                        const int i = 16 * ib + (e >> 4), j = 16 * jb + (e & 15);
+                                        double v = Pg[(size_t)i * NP + j];
+                                        if (i == j && i >= n)
+                                                v = 1.0;
+                                        Lt[tl * TSZ + (e >> 4) * TLD + (e & 15)] = v;
+                                }
                         }
                 }
                 __syncthreads();
@@ -466,18 +476,20 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 // order.  Landmark rows are affine in the sigma points, the +- pairs cancel, and sum_i w_i x_i(k) = (sum_i w_i) X(k)
                 // exactly (the sum of the binary32 weights is not 1: that factor is part of the reference's arithmetic).
                 const double wsum = fma((double)(m - 1), w_i, w_0); // w_0 + (m - 1) w_i: the m - 1 equal weights summed in one step
-                for (int k = tid; k < NP; k += SMALL_WG)
+                // (round 4: the three pose rows are summed by a wave each -- lane partial sums in index order, combined by DPP adds -- instead of 2 N + 5
+                // sequential additions by one thread: the order of the additions differs from the reference's, the result by an ulp of the pose)
+                if (tid < 3 * 64)
                 {
+                        const int k = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
                         double acc = 0.0;
-                        if (k < 3)
-                        {
-                                for (int i = 0; i < m; ++i)
-                                        acc += sW[i] * sXP[k * UL::MP + i];
-                        }
-                        else if (k < n)
-                                acc = wsum * sX[k];
-                        sXbar[k] = acc;
+                        for (int i = lane; i < m; i += 64)
+                                acc += sW[i] * sXP[k * UL::MP + i];
+                        acc = wave_sum_dpp(acc);
+                        if (lane == 63)
+                                sXbar[k] = acc;
                 }
+                for (int k = 3 + tid; k < NP; k += SMALL_WG)
+                        sXbar[k] = (k < n) ? wsum * sX[k] : 0.0;
                 __syncthreads();
 
                 // ---- the few sigma points whose POSE differs from the centre's: L is lower triangular, so only the columns c < 3 of L move the pose, and the
@@ -608,8 +620,8 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                                 if (k == 2)
                                                         zd = (double)normalizeAngle((float)zd);
                                                 sY[k] = zd;
-                                                sZpred[k] = zp;
                                                 sS[k] = sacc;
+                                                sZpred[k] = zp;
                                         }
                                 }
                                 else if (r < 3 + nl)
@@ -783,19 +795,10 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 // ---- landmark block of P.  For two landmark entries a, b the sigma points are affine,
                 // d_i(a) = +-w L(a,c_i) + delta_a with delta_a = X(a) - Xbar(a) (not zero: the binary32 weights do not sum to 1),
                 // so the +- pairs cancel and, exactly,  sum_i w_i d_i(a) d_i(b) = (sum_i w_i) delta_a delta_b + 2 w_1 w^2 (L L^T)(a,b),
-                // with L L^T = P, the covariance that was just factored: an in-place scale + rank-1 term instead of a GEMM.
-                {
-                        const double cll = 2.0 * w_i * wsp * wsp;
-                        for (int idx = tid; idx < (n - 3) * 16 * nt; idx += SMALL_WG)
-                        {
-                                const int a = 3 + idx / (16 * nt), bb = idx - (a - 3) * (16 * nt);
-                                if (bb >= 3 && bb < n)
-                                {
-                                        const double da = sX[a] - sXbar[a], db = sX[bb] - sXbar[bb];
-                                        Pg[(size_t)a * NP + bb] = fma(cll, Pg[(size_t)a * NP + bb], wsum * da * db);
-                                }
-                        }
-                }
+                // with L L^T = P, the covariance that was just factored: a scale + rank-1 term instead of a GEMM -- applied (round 4) inside the pass
+                // that subtracts K S K^T at the end of the callback (gemm_wabt<GEMM_SUBTRACT_SYM>, pdelta): nothing between here and there reads the
+                // predicted landmark block, and a read-modify-write pass of its own over P cost 19 k cycles and 330 KB of L2 traffic per callback.
+                const double cll = 2.0 * w_i * wsp * wsp;
                 __syncthreads();
                 ASLAM_STAMP(4);
 
@@ -851,14 +854,19 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         // ---- X = X + K Zdiff (ukf.cpp:389)
                         for (int k = tid; k < NP; k += SMALL_WG)
                         {
+                                double dl = 0.0;
                                 if (k < n)
+                                {
+                                        dl = sX[k] - sXbar[k]; // delta of the predicted landmark block (sZpred = sT is dead by now)
                                         sX[k] = sXbar[k] + sU[k] + sGv[k] * (qt * inv_den);
+                                }
                                 else
                                         sGv[k] = 0.0;
+                                sZpred[k] = dl;
                         }
                         ASLAM_STAMP(9);
                         // ---- P = P - K S K^T (ukf.cpp:391) = P - W W^T - g g^T / (1 - q.q)
-                        gemm_wabt<NT, GEMM_SUBTRACT_SYM>(Kg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den);
+                        gemm_wabt<NT, GEMM_SUBTRACT_SYM>(Kg, Kg, NP, nt, nullptr, nt, Pg, nullptr, 0.0, n, stage, tid, sGv, inv_den, sZpred, cll, wsum);
                 }
 
                 ASLAM_STAMP(10);
