@@ -1,4 +1,4 @@
-OUT=gpurun_out/r3b1
+OUT=gpurun_out/${1:-r4b1}
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -o t -- python3 bench.py --batch 1 --no-sub --no-legs --cpu-sample 0 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/err.txt
 python3 - $OUT <<"PY"
