@@ -1,4 +1,4 @@
-OUT=gpurun_out/r3q
+OUT=gpurun_out/${1:-r4s}
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 tools/gpu_stamps_ukf.py > $OUT/ukf_phase_stamps.txt 2>&1
 python3 tools/gpu_stamps.py > $OUT/ekf_phase_stamps.txt 2>&1
