@@ -250,10 +250,22 @@ __device__ __forceinline__ void gemm_l_et(const double *Lt, const double *ETg, i
                 acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
         }
         const int npairs = rows * 8;
+        // columns 16 ks .. 16 ks + 15 of E^T for all rows: element pairs, one 16-byte load per pair, fetched into registers one slab ahead (the slab
+        // area is single: the loads of slab ks + 1 fly while slab ks is multiplied)
+        double2 pre[2];
+        auto fetch = [&](int ks) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                        const int pi = tid + u * SMALL_WG;
+                        if (pi < npairs)
+                                pre[u] = *reinterpret_cast<const double2 *>(ETg + (size_t)(pi >> 3) * NP + 16 * ks + (pi & 7) * 2);
+                }
+        };
+        fetch(0);
         __syncthreads(); // whatever lived in the slab area before is dead from here on
         for (int ks = 0; ks < nt; ++ks)
         {
-                // stage columns 16 ks .. 16 ks + 15 of E^T for all rows: element pairs, one 16-byte load per pair
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                 {
@@ -261,12 +273,13 @@ __device__ __forceinline__ void gemm_l_et(const double *Lt, const double *ETg, i
                         if (pi < npairs)
                         {
                                 const int r = pi >> 3, c2 = (pi & 7) * 2;
-                                const double2 v = *reinterpret_cast<const double2 *>(ETg + (size_t)r * NP + 16 * ks + c2);
-                                slab[r * LD + c2] = v.x;
-                                slab[r * LD + c2 + 1] = v.y;
+                                slab[r * LD + c2] = pre[u].x;
+                                slab[r * LD + c2 + 1] = pre[u].y;
                         }
                 }
                 __syncthreads();
+                if (ks + 1 < nt)
+                        fetch(ks + 1);
 #pragma unroll
                 for (int q = 0; q < TPW; ++q)
                 {
