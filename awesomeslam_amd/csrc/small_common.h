@@ -315,6 +315,18 @@ template <int NT> __device__ __forceinline__ void load_row_block(d4 (&acc)[NT], 
         }
 }
 
+/// Physical wave -> role index of the fused factorisations (round 4).  The twelve waves of the workgroup sit three to a SIMD (wave p on SIMD p & 3); the diagonal
+/// wave (role DW) is the serial spine, and every v_mfma_f64 another wave of its SIMD issues holds that SIMD's FP64 pipe for 64 cycles.  Roles DW, DW + 1, DW + 2 -- the
+/// diagonal wave and two helper waves, which only take panel / trailing shares and no forward-substitution step -- go to physical waves 3, 7, 11 (one SIMD); the
+/// row-block roles and the remaining helpers fill the other nine in order.
+__device__ __forceinline__ int role_of_wave(int p, int DW)
+{
+        if ((p & 3) == 3)
+                return DW + (p >> 2);
+        const int idx = p - (p >> 2);
+        return idx < DW ? idx : idx + 3;
+}
+
 // ---- pieces of the fused factorisation, shared by the three wave roles below -------------------------------
 /// this wave's share of panel kb: L(ib,kb) = S(ib,kb) * Linv(kb)^T for ib = kb+1+wave, +SMALL_WAVES, ...
 __device__ __forceinline__ void chol_panel_share(double *Lt, const double *Dinv, int nt, int kb, int wave, int li, int lg)
@@ -341,7 +353,8 @@ __device__ __forceinline__ void chol_panel_share(double *Lt, const double *Dinv,
 }
 
 /// this wave's share of the trailing update after panel kb: S(ib,jb) -= L(ib,kb) L(jb,kb)^T for kb < jb <= ib, without
-/// (kb+1,kb+1), which belongs to the diagonal wave; `widx` in [0, SMALL_WAVES-1) numbers the non-diagonal waves
+/// (kb+1,kb+1), which belongs to the diagonal wave; `widx` in [0, SMALL_WAVES-1) numbers the non-diagonal waves.  (Round 4 also tried leaving the two
+/// helper roles that share the diagonal wave's SIMD idle -- role_of_wave -- so that nothing else issues there: no gain, 112 k -> 115 k cycles.)
 __device__ __forceinline__ void chol_trailing_share(double *Lt, int nt, int kb, int widx, int li, int lg)
 {
         const int m = nt - kb - 1;
@@ -565,7 +578,7 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
 #endif
         static_assert(NT < SMALL_WAVES, "one wave beyond the row-block waves is needed for the diagonal tiles");
         constexpr int DW = NT;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // scalar: the role branches are uniform
+        const int wave = role_of_wave(__builtin_amdgcn_readfirstlane(tid >> 6), DW), lane = tid & 63; // scalar: the role branches are uniform
         const int li = lane & 15, lg = lane >> 4;
         if (wave < nt)
         {
@@ -656,7 +669,7 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
 {
         static_assert(NT + 1 < SMALL_WAVES, "row-block waves, the diagonal wave and at least one helper");
         constexpr int DW = NT;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int wave = role_of_wave(__builtin_amdgcn_readfirstlane(tid >> 6), DW), lane = tid & 63;
         const int li = lane & 15, lg = lane >> 4;
         if (tid < 16 * nt)
                 *tile_elem(Lt, tid, tid) += (tid < n_true) ? r : 1.0; // S = P~ + R; padding decouples
@@ -815,7 +828,7 @@ template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt,
 {
         static_assert(NT < SMALL_WAVES, "one wave is reserved for the diagonal tiles");
         constexpr int DW = NT;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int wave = role_of_wave(__builtin_amdgcn_readfirstlane(tid >> 6), DW), lane = tid & 63;
         const int li = lane & 15, lg = lane >> 4;
         if (wave == DW)
         {
