@@ -228,7 +228,11 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 ASLAM_STAMP(4);
                 // S = Pt + R = L L^T (ekf.cpp:300); r*Kt = r I - r^2 S^-1 -> the tiles (= (I - K H) P in measurement coordinates,
                 // ekf.cpp:301,310); u = Kt Y = Y - r S^-1 Y
+#ifdef ASLAM_STAMPS
+                cholesky_inverse_tiles<NT>(Lt, Dinv, nt, n, sY, sU, L.sTv, r_meas, tid, &sm.status, (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr);
+#else
                 cholesky_inverse_tiles<NT>(Lt, Dinv, nt, n, sY, sU, L.sTv, r_meas, tid, &sm.status);
+#endif
                 ASLAM_STAMP(5);
                 __syncthreads();
                 ASLAM_STAMP(6);

@@ -665,8 +665,16 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
 /// as cholesky_forward_rows; `Tv`: LDS scratch of 16*NT doubles.  Ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv, int nt, int n_true, const double *Y, double *U,
-                                                       double *Tv, double r, int tid, uint32_t *status)
+                                                       double *Tv, double r, int tid, uint32_t *status, unsigned long long *wave_busy = nullptr)
 {
+#ifdef ASLAM_STAMPS
+        // diagnostic builds: per role, shader cycles busy between the barriers of the factorisation loop (slot 0) and, for the diagonal wave, inside the
+        // look-ahead (update + factorisation of the next diagonal tile: slot 1)
+        unsigned long long tb_[3] = {0, 0, 0}, tm_ = __builtin_amdgcn_s_memtime(), tn_;
+#define WB(i) (tn_ = __builtin_amdgcn_s_memtime(), tb_[i] += tn_ - tm_, tm_ = tn_)
+#else
+#define WB(i)
+#endif
         static_assert(NT + 1 < SMALL_WAVES, "row-block waves, the diagonal wave and at least one helper");
         constexpr int DW = NT;
         const int wave = role_of_wave(__builtin_amdgcn_readfirstlane(tid >> 6), DW), lane = tid & 63;
@@ -687,13 +695,18 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                 __syncthreads(); // (the diagonal wave factors tile 0)
                 for (int kb = 0; kb < nt; ++kb)
                 {
+                        WB(1);
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
+                        WB(1);
                         if (kb >= rb) // block columns left of the diagonal block of this row block stay zero
                                 forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
                         chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
                 }
+                WB(1);
                 // acc = rows of L^-T; L is dead: its tiles take L^-1 (tile (cb, rb) = transpose of block (rb, cb) of L^-T)
 #pragma unroll
                 for (int cb = 0; cb < NT; ++cb)
@@ -759,11 +772,16 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                 __syncthreads();
                 for (int kb = 0; kb < nt; ++kb)
                 {
+                        WB(1);
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
+                        WB(0);
                         __syncthreads();
+                        WB(1);
                         ok = chol_lookahead(Lt, Dinv, nt, kb, lane, li, lg) && ok;
+                        WB(2);
                         __syncthreads();
                 }
+                WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
                 __builtin_amdgcn_s_setprio(0);
@@ -819,6 +837,14 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                 }
                 __syncthreads(); // [B]
         }
+#ifdef ASLAM_STAMPS
+        if (wave_busy && lane == 0)
+        {
+                wave_busy[2 * wave] += tb_[0];     // busy inside the factorisation loop (diagonal wave: its panel share only)
+                wave_busy[2 * wave + 1] += tb_[2]; // diagonal wave: update + factorisation of the next diagonal tile
+        }
+#endif
+#undef WB
         __syncthreads();
 }
 
