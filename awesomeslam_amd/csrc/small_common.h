@@ -692,6 +692,21 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                                 acc[cb][q] = (cb == rb && li == lg + 4 * q) ? 1.0 : 0.0;
+                // Round 4: Y^T rides along as right-hand side row n (n is odd, so row n is a padding row of the last row block: its identity row is not
+                // needed -- the padding decouples -- and is put back below): the forward substitution turns it into t^T = (L^-1 Y)^T, the first of the two
+                // triangular mat-vecs of S^-1 Y = L^-T (L^-1 Y), which one helper wave used to do tile by tile behind the loop while eleven waves waited
+                // (~ 25 k of the phase's 111 k cycles at n = 131); the second is a dot product of every row-block wave's own registers with t (below).
+                const int nrow = n_true - 16 * (nt - 1); // row n inside the last row block
+                const bool yrow = (rb == nt - 1) && (li == nrow);
+                if (rb == nt - 1)
+                {
+#pragma unroll
+                        for (int cb = 0; cb < NT; ++cb)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                        if (yrow && cb < nt)
+                                                acc[cb][q] = Y[16 * cb + lg + 4 * q]; // (zero from n on)
+                }
                 __syncthreads(); // (the diagonal wave factors tile 0)
                 for (int kb = 0; kb < nt; ++kb)
                 {
@@ -700,13 +715,26 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                         WB(0);
                         __syncthreads();
                         WB(1);
-                        if (kb >= rb) // block columns left of the diagonal block of this row block stay zero
+                        if (kb >= rb || rb == nt - 1) // block columns left of the diagonal block of this row block stay zero (the last one carries Y^T: all of them)
                                 forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
                         chol_trailing_share(Lt, nt, kb, wave, li, lg);
                         WB(0);
                         __syncthreads();
                 }
                 WB(1);
+                // row n of the last row block is t^T = (L^-1 Y)^T: publish it, and give the row its identity values back
+                if (rb == nt - 1)
+                {
+#pragma unroll
+                        for (int cb = 0; cb < NT; ++cb)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                        if (yrow && cb < nt)
+                                        {
+                                                Tv[16 * cb + lg + 4 * q] = acc[cb][q];
+                                                acc[cb][q] = (16 * cb + lg + 4 * q == n_true) ? 1.0 : 0.0;
+                                        }
+                }
                 // acc = rows of L^-T; L is dead: its tiles take L^-1 (tile (cb, rb) = transpose of block (rb, cb) of L^-T)
 #pragma unroll
                 for (int cb = 0; cb < NT; ++cb)
@@ -718,52 +746,26 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                                         Lt[tile_index(cb, rb) * TSZ + (lg + 4 * q) * TLD + li] = acc[cb][q];
                         }
                 }
-                __syncthreads(); // [A] L^-1 complete
-                // (S^-1)(rb, jb) = sum_{k >= rb} Linv(k, rb)^T Linv(k, jb) for jb <= rb, in registers
-#pragma unroll
-                for (int jb = 0; jb < NT; ++jb)
+                __syncthreads(); // [A] L^-1 complete, t published
+                // U = Kt Y = Y - r S^-1 Y = Y - r L^-T t: this wave's rows of L^-T are its accumulators
                 {
-                        if (jb <= rb)
+                        double pu = 0.0;
+#pragma unroll
+                        for (int cb = 0; cb < NT; ++cb)
                         {
-                                d4 o = {0.0, 0.0, 0.0, 0.0};
-                                for (int k = rb; k < nt; ++k)
+                                if (cb >= rb && cb < nt)
                                 {
-                                        const double *A = Lt + tile_index(k, rb) * TSZ, *B = Lt + tile_index(k, jb) * TSZ;
-                                        double a[4], bq[4];
 #pragma unroll
                                         for (int q = 0; q < 4; ++q)
-                                        {
-                                                a[q] = A[(lg + 4 * q) * TLD + li];
-                                                bq[q] = B[(lg + 4 * q) * TLD + li];
-                                        }
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q)
-                                                o = mfma_f64(a[q], bq[q], o);
-                                }
-                                acc[jb] = o; // C layout: element (row lg + 4 q, column li) of the tile
-                        }
-                }
-                __syncthreads(); // [B] nobody reads L^-1 any more
-                const double r2 = r * r;
-#pragma unroll
-                for (int jb = 0; jb < NT; ++jb)
-                {
-                        if (jb <= rb)
-                        {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                {
-                                        const int i = 16 * rb + lg + 4 * q, j = 16 * jb + li;
-                                        if (j <= i)
-                                        {
-                                                double v = 0.0;
-                                                if (i < n_true) // (j <= i < n)
-                                                        v = ((i == j) ? r : 0.0) - r2 * acc[jb][q];
-                                                Lt[tile_index(rb, jb) * TSZ + (lg + 4 * q) * TLD + li] = v;
-                                        }
+                                                pu = fma(acc[cb][q], Tv[16 * cb + lg + 4 * q], pu);
                                 }
                         }
+                        pu += __shfl_xor(pu, 16);
+                        pu += __shfl_xor(pu, 32);
+                        if (lg == 0)
+                                U[16 * rb + li] = Y[16 * rb + li] - r * pu;
                 }
+                WB(2); // (row-block roles: everything behind the factorisation loop -- L^-1 to the tiles, the L^-T L^-1 product, r I - r^2 S^-1)
         }
         else if (wave == DW)
         {
@@ -786,7 +788,6 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                         *status |= 4u; // ASLAM_ST_NOT_PD
                 __builtin_amdgcn_s_setprio(0);
                 __syncthreads(); // [A]
-                __syncthreads(); // [B]
         }
         else
         {
@@ -799,43 +800,77 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                         __syncthreads();
                 }
                 __syncthreads(); // [A]
-                if (wave == DW + 1)
+        }
+        // ---- S^-1 = L^-T L^-1 on ALL twelve waves (round 4: the row-block waves did it alone, row block rb its rb + 1 tiles of (nt - rb) products each --
+        // up to 25 tile products on one wave while three waves idled): (S^-1)(rb, jb) = sum_{k >= rb} Linv(k, rb)^T Linv(k, jb), jb <= rb; the 45 lower tiles
+        // are dealt in snake order over the waves (costs fall with the tile index: <= 15 products per wave), two products in flight per tile
+        {
+                const int pw = __builtin_amdgcn_readfirstlane(tid >> 6); // (any bijection wave -> 0 .. 11 will do)
+                const int ntl = nt * (nt + 1) / 2;
+                constexpr int TPW = (NT * (NT + 1) / 2 + SMALL_WAVES - 1) / SMALL_WAVES;
+                d4 out[TPW];
+                int orb[TPW], ojb[TPW];
+#pragma unroll
+                for (int qq = 0; qq < TPW; ++qq)
                 {
-                        // U = Kt Y = Y - r S^-1 Y with S^-1 Y = Linv^T (Linv Y): two triangular tile mat-vecs by this one wave
-                        for (int ib = 0; ib < nt; ++ib)
+                        const int tl = SMALL_WAVES * qq + ((qq & 1) ? SMALL_WAVES - 1 - pw : pw);
+                        int rb = 0, jb = 0;
+                        d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = {0.0, 0.0, 0.0, 0.0};
+                        if (tl < ntl)
                         {
-                                double p = 0.0;
-                                for (int jb = 0; jb <= ib; ++jb)
+                                rb = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+                                while ((rb + 1) * (rb + 2) / 2 <= tl)
+                                        ++rb;
+                                while (rb * (rb + 1) / 2 > tl)
+                                        --rb;
+                                jb = tl - rb * (rb + 1) / 2;
+                                for (int k = rb; k < nt; k += 2)
                                 {
-                                        const double *Tt = Lt + tile_index(ib, jb) * TSZ;
+                                        const bool two = (k + 1 < nt);
+                                        const double *A0 = Lt + tile_index(k, rb) * TSZ, *B0 = Lt + tile_index(k, jb) * TSZ;
+                                        const double *A1 = Lt + tile_index(two ? k + 1 : k, rb) * TSZ, *B1 = Lt + tile_index(two ? k + 1 : k, jb) * TSZ;
+                                        double a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
                                         for (int q = 0; q < 4; ++q)
-                                                p = fma(Tt[li * TLD + lg + 4 * q], Y[16 * jb + lg + 4 * q], p);
+                                        {
+                                                a0[q] = A0[(lg + 4 * q) * TLD + li];
+                                                b0[q] = B0[(lg + 4 * q) * TLD + li];
+                                                a1[q] = two ? A1[(lg + 4 * q) * TLD + li] : 0.0;
+                                                b1[q] = B1[(lg + 4 * q) * TLD + li];
+                                        }
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                        {
+                                                o0 = mfma_f64(a0[q], b0[q], o0);
+                                                o1 = mfma_f64(a1[q], b1[q], o1);
+                                        }
                                 }
-                                p += __shfl_xor(p, 16);
-                                p += __shfl_xor(p, 32);
-                                if (lg == 0)
-                                        Tv[16 * ib + li] = p;
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        for (int jb = 0; jb < nt; ++jb)
-                        {
-                                double p = 0.0;
-                                for (int ib = jb; ib < nt; ++ib)
-                                {
-                                        const double *Tt = Lt + tile_index(ib, jb) * TSZ;
+                        out[qq] = o0 + o1; // C layout: element (row lg + 4 q, column li) of the tile
+                        orb[qq] = (tl < ntl) ? rb : -1;
+                        ojb[qq] = jb;
+                }
+                __syncthreads(); // [B] nobody reads L^-1 any more
+                const double r2 = r * r;
 #pragma unroll
-                                        for (int q = 0; q < 4; ++q)
-                                                p = fma(Tt[(lg + 4 * q) * TLD + li], Tv[16 * ib + lg + 4 * q], p);
+                for (int qq = 0; qq < TPW; ++qq)
+                {
+                        if (orb[qq] >= 0)
+                        {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                {
+                                        const int i = 16 * orb[qq] + lg + 4 * q, j = 16 * ojb[qq] + li;
+                                        if (j <= i)
+                                        {
+                                                double v = 0.0;
+                                                if (i < n_true) // (j <= i < n)
+                                                        v = ((i == j) ? r : 0.0) - r2 * out[qq][q];
+                                                Lt[tile_index(orb[qq], ojb[qq]) * TSZ + (lg + 4 * q) * TLD + li] = v;
+                                        }
                                 }
-                                p += __shfl_xor(p, 16);
-                                p += __shfl_xor(p, 32);
-                                if (lg == 0)
-                                        U[16 * jb + li] = Y[16 * jb + li] - r * p;
                         }
                 }
-                __syncthreads(); // [B]
         }
 #ifdef ASLAM_STAMPS
         if (wave_busy && lane == 0)
