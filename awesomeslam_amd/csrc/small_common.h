@@ -875,7 +875,7 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
 #ifdef ASLAM_STAMPS
         if (wave_busy && lane == 0)
         {
-                wave_busy[2 * wave] += tb_[0];     // busy inside the factorisation loop (diagonal wave: its panel share only)
+                wave_busy[2 * wave] += (wave == DW) ? tb_[1] : tb_[0]; // busy inside the factorisation loop (diagonal wave: its WAIT at the barriers instead)
                 wave_busy[2 * wave + 1] += tb_[2]; // diagonal wave: update + factorisation of the next diagonal tile
         }
 #endif
