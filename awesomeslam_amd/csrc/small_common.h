@@ -470,11 +470,17 @@ __device__ __forceinline__ bool chol_lookahead(double *Lt, double *Dinv, int nt,
 
 /// Forward-only tail of the fused solve (UKF): the row block in acc is W = Src L^-T.  Store it, and let the wave that owns
 /// row `qrow` publish that row (q^T) to LDS.
-template <int NT> __device__ __forceinline__ void forward_store(const d4 (&acc)[NT], double *Dst, int rb, int nt, int qrow, double *Q, int lane)
+/// `scratch`: one tile (TSZ doubles) of LDS per wave.  In the accumulator layout a lane holds the columns lg + 4 r of row li: stored directly, an instruction writes 8 bytes
+/// per lane into sixteen 32-byte row segments (36 such instructions per row block: 24 k cycles behind the loop, per-role stamps of round 4); through the scratch tile a lane
+/// stores four consecutive columns of a row as 32 contiguous bytes and four lanes cover a 128-byte line.
+template <int NT>
+__device__ __forceinline__ void forward_store(const d4 (&acc)[NT], double *Dst, int rb, int nt, int qrow, double *Q, int lane, double *scratch)
 {
         constexpr int NP = 16 * NT;
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
         const int li = lane & 15, lg = lane >> 4;
-        double *outp = Dst + (size_t)(16 * rb + li) * NP + lg;
+        const int orow = lane >> 2, oc = 4 * (lane & 3); // this lane's row and first column of the tile on the way out
+        double *outp = Dst + (size_t)(16 * rb + orow) * NP + oc;
         const bool mine = (16 * rb + li == qrow);
 #pragma unroll
         for (int cb = 0; cb < NT; ++cb)
@@ -484,10 +490,18 @@ template <int NT> __device__ __forceinline__ void forward_store(const d4 (&acc)[
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                         {
-                                outp[16 * cb + 4 * r] = acc[cb][r];
+                                scratch[li * TLD + lg + 4 * r] = acc[cb][r];
                                 if (mine)
                                         Q[16 * cb + lg + 4 * r] = acc[cb][r];
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const double *sr = scratch + orow * TLD + oc;
+                        const dbl2 v0 = {sr[0], sr[1]}, v1 = {sr[2], sr[3]};
+                        *reinterpret_cast<dbl2 *>(outp + 16 * cb) = v0;
+                        *reinterpret_cast<dbl2 *>(outp + 16 * cb + 2) = v1;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier(); // (the next tile overwrites the scratch)
                 }
         }
 }
@@ -523,6 +537,36 @@ __device__ __forceinline__ void row_dots(const d4 (&acc)[NT], int rb, int nt, co
 }
 
 /// T = L^-1 Y for a vector (LDS), tile by tile, by ONE wave: T_kb = Linv(kb) (Y_kb - sum_{j<kb} L(kb,j) T_j)
+/// Block kb alone (blocks 0 .. kb-1 of T done): what a helper wave of cholesky_forward_rows does in block column kb of the fused loop (round 4) -- row kb of L and the
+/// inverse of diagonal tile kb are final by then, and the wave has nothing else to do -- so that T is complete when the loop ends; the diagonal wave used to
+/// run the whole chain behind the loop (17 k cycles at n = 131) while the row-block waves waited for T.
+__device__ __forceinline__ void forward_vector_block(const double *Lt, const double *Dinv, int kb, const double *Y, double *T, int lane)
+{
+        const int li = lane & 15, lg = lane >> 4;
+        double p = 0.0;
+        for (int j = 0; j < kb; ++j)
+        {
+                const double *Lkj = Lt + tile_index(kb, j) * TSZ;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                        p = fma(Lkj[li * TLD + lg + 4 * s], T[16 * j + lg + 4 * s], p);
+        }
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        const double r = Y[16 * kb + li] - p; // every lane of row li holds it
+        const double *Di = Dinv + kb * TSZ;
+        double q = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+                q = fma(Di[li * TLD + lg + 4 * s], __shfl(r, lg + 4 * s), q);
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (lg == 0)
+                T[16 * kb + li] = q;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // the next block reads T through LDS
+}
+
 __device__ __forceinline__ void forward_vector(const double *Lt, const double *Dinv, int nt, const double *Y, double *T, int lane)
 {
         const int li = lane & 15, lg = lane >> 4;
@@ -598,7 +642,7 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
                         __syncthreads();
                 }
                 WB(1);
-                forward_store<NT>(acc, Dst, wave, nt, qrow, Qv, lane);
+                forward_store<NT>(acc, Dst, wave, nt, qrow, Qv, lane, Dinv + wave * TSZ); // (the inverted diagonal tiles are dead behind the loop: a scratch tile per wave)
                 __syncthreads(); // Qv and Tv (diagonal wave) are in LDS
                 row_dots<NT>(acc, wave, nt, Tv, Qv, U, G, lane);
                 WB(2);
@@ -623,7 +667,7 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
                 WB(1);
                 if (!ok && lane == 0)
                         *status |= 4u; // ASLAM_ST_NOT_PD
-                forward_vector(Lt, Dinv, nt, Y, Tv, lane);
+                // (Tv = L^-1 Y: helper role DW + 1, block by block inside the loop)
                 __syncthreads();
                 __builtin_amdgcn_s_setprio(0);
         }
@@ -637,6 +681,8 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
                         WB(0);
                         __syncthreads();
                         WB(1);
+                        if (wave == DW + 1)
+                                forward_vector_block(Lt, Dinv, kb, Y, Tv, lane); // row kb of L and Linv(kb) are final: block kb of Tv = L^-1 Y
                         chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
                         WB(0);
                         __syncthreads();

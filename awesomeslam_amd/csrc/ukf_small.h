@@ -840,7 +840,11 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                 //   K S K^T  = Tc S^-1 Tc^T   = W W^T + g g^T / (1 - q.q)
                 // so neither K nor a backward substitution is needed (ukf.cpp:378-391 evaluated in this form).
                 double *const sT = sZpred, *const sQ = sVv; // both dead by now
+#ifdef ASLAM_STAMPS
+                cholesky_forward_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, tid, &sm.status, sT, sQ, sGv, n, (blockIdx.x == 0 && d.dbg) ? d.dbg + 16 : nullptr);
+#else
                 cholesky_forward_rows<NT>(Tcg, Kg, Lt, Dinv, nt, sY, sU, tid, &sm.status, sT, sQ, sGv, n);
+#endif
                 ASLAM_STAMP(8);
                 {
                         // q.q and q.t: the same sums in every wave
