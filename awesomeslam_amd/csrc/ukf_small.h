@@ -214,9 +214,27 @@ __device__ __forceinline__ void gemm_wabt(const double *A, const double *B, int 
                                                 old = fma(pcll, old, pwsum * pdelta[i] * pdelta[j]);
                                         const double nv = old - (gvec ? fma(gscale * gvec[i], gvec[j], acc[q][r]) : acc[q][r]);
                                         Cg[(size_t)i * NP + j] = nv;
-                                        if (ib != jb)
-                                                Cg[(size_t)j * NP + i] = nv;
+                                        acc[q][r] = nv; // (the mirror image is stored below, tile by tile, through an LDS scratch tile)
                                 }
+                        }
+                        if (MODE == GEMM_SUBTRACT_SYM && ib != jb)
+                        {
+                                // mirror image of the tile: element (i, j) -> (j, i).  Straight from the accumulators that is 8 bytes per lane into sixteen 32-byte
+                                // row segments; through a scratch tile (the staging area is free behind the K loop) a lane stores four consecutive entries of a row
+                                typedef double dbl2 __attribute__((ext_vector_type(2)));
+                                double *scr = stage + wave * TSZ;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                        scr[li * TLD + lg + 4 * r] = acc[q][r]; // scr[column of the tile][row of the tile]
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                const int orow = lane >> 2, oc = 4 * (lane & 3); // row of the MIRRORED tile (= column li of the tile), its first column
+                                const double *sr = scr + orow * TLD + oc;
+                                double *dst = Cg + (size_t)(16 * jb + orow) * NP + 16 * ib + oc;
+                                *reinterpret_cast<dbl2 *>(dst) = (dbl2){sr[0], sr[1]};
+                                *reinterpret_cast<dbl2 *>(dst + 2) = (dbl2){sr[2], sr[3]};
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
                         }
                 }
         }
