@@ -1068,7 +1068,10 @@ __global__ __launch_bounds__(256) void large_syrk(DevView d, LargeView<T> lv, in
 /// ways (the X update's workgroups inside this launch: 2436 us against 1997 + 324 per 256 filters; on a side stream: 31.7 k against 36.4 k filter-steps/s)
 /// and both lose: at this kernel's register footprint the latency-bound X-update workgroups take slots while the matrix pipes idle, and next to it they
 /// fight it for L2 (profiles/r04_experiments.md section 1).
-constexpr int XU_ROWS = 8;
+#ifndef ASLAM_XU_ROWS
+#define ASLAM_XU_ROWS 8
+#endif
+constexpr int XU_ROWS = ASLAM_XU_ROWS; // (rows per wave of large_x_update_rows; 4 and 16 measured in round 4: profiles/r04_experiments.md)
 ///
 /// PL = 1 (round 4; the default chain): V arrives ALREADY SPLIT -- large_trsm_bf16 stores the three bf16 planes of every solved block next to the binary32 V
 /// (`vpl`: [B][3][NP][NP], the columns of every 64-block permuted as in LPlanes; the permutation stays inside a 32-column half, and a slab's contraction
