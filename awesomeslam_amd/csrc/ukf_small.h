@@ -813,6 +813,9 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                                                 DZg[(size_t)k * MP + i] = 0.0;
                                         for (int c = lane; c < 16 * nt; c += 64)
                                                 ETg[(size_t)k * NP + c] = 0.0;
+                                        if (lane < 3)
+                                                Tcg[(size_t)lane * NP + k] = 0.0; // the pose rows of Tc are written column by column by these waves: a padding column must not keep
+                                                                                  // what an earlier, larger state left there (aslam_reset: tests/test_gpu_ukf.py, full-batch case)
                                         if (lane == 0)
                                         {
                                                 sY[k] = 0.0;

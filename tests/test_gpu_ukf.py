@@ -166,3 +166,45 @@ def test_not_pd_is_flagged_when_the_reference_covariance_goes_indefinite(L, seed
             break
     print(f"ukf ring L={L}: oracle P indefinite after callback {t_oracle}, device ASLAM_ST_NOT_PD after callback {t_dev}")
     assert t_dev is not None and 0 <= t_dev - t_oracle <= 1
+
+
+@pytest.mark.parametrize("kind", ["ukf", "ekf"])
+def test_identical_trajectories_at_the_benchmarked_batch(kind, built):
+    """256 copies of ONE 64-landmark trajectory through the single-CU kernel at the batch bench.py times (one workgroup on every CU): every filter
+    runs the same instructions on the same numbers, so poses and covariances must agree BIT FOR BIT whatever the neighbours and the memory system
+    are doing -- the kernels synchronise their twelve waves through barriers, LDS scratch tiles that change hands between phases (round 4: the
+    slab of E^T and the store tiles in the area of the inverted diagonal tiles, the mirror tiles in the staging area) and, in HBM / L2, through
+    the DZ / E^T / Tc / W scratch of the UKF -- and filter 0 must agree with the CPU oracle at the usual bars."""
+    import torch
+    from awesomeslam_amd.core import Core
+    from oracle.c_oracle import CFilter
+
+    L, T, B = 64, 120, 256
+    tr1 = tg.make_traces(L, T, B=1, seed=48)
+    tr = tr1.select([0] * B)
+    core = Core(kind, tg.dim_cap(L), batch=B, max_obs=tr.max_obs, max_wait=256)
+    core.set_trace(tr)
+    poses = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    dims = torch.zeros((B, T), dtype=torch.int32, device="cuda")
+    half = torch.zeros((B, T // 2, 3), dtype=torch.float64, device="cuda")
+    core.replay(0, T // 2, half.data_ptr(), None)  # (a first, shorter launch: the contexts' scratch has been used when the checked replay starts)
+    torch.cuda.synchronize()
+    core.reset()
+    core.replay(0, T, poses.data_ptr(), dims.data_ptr())
+    torch.cuda.synchronize()
+    poses, dims = poses.cpu().numpy(), dims.cpu().numpy()
+    assert dims[0, -1] == tg.full_dim(L) and (dims == dims[0]).all()
+    differing = [b for b in range(B) if not np.array_equal(poses[b], poses[0])]
+    assert not differing, f"{len(differing)} of {B} identical trajectories left the pose stream of filter 0 (first: {differing[:5]})"
+    X0, Z0, P0 = core.state(0)
+    for b in (1, 17, 100, 255):
+        X, Z, P = core.state(b)
+        assert core.status(b) == 0 and np.array_equal(X, X0) and np.array_equal(Z, Z0) and np.array_equal(P, P0), f"filter {b} differs from filter 0"
+    o = CFilter(kind, tg.dim_cap(L))
+    po, do = o.replay(tr1[0])
+    Xo, Zo, Po = o.state()
+    assert np.array_equal(dims[0], do) and np.array_equal(Z0, Zo)
+    errs = rel_err(poses[0], po), rel_err(X0, Xo), cov_err(P0, Po)
+    print(f"{kind} L={L} batch {B}, filter 0 against the oracle: rel err pose/X/P = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    assert max(errs) < REL_TOL
+    core.close()
