@@ -58,7 +58,7 @@ struct aslam_ctx
         size_t lds_bytes;
         std::string kernel_name;
 #if ASLAM_HAVE_UKF
-        UkfView ukf;
+        UkfView ukf = {};
 #endif
         // large-state path (n > 143): typed covariance buffers, one launch chain per callback
         bool large = false;
@@ -207,6 +207,16 @@ int init_state(aslam_ctx *c)
         HIP_TRY(hipMemcpy(d.A, A.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice));
         if (c->large)
                 return init_state_large(c);
+#if ASLAM_HAVE_UKF
+        if (c->ukf.D)
+        { // a reset context is a fresh one: the scratch too (ukf_alloc zeroes it; the kernels rely on never-written padding staying zero)
+                const size_t MP = (size_t)c->ukf.MP;
+                HIP_TRY(hipMemset(c->ukf.D, 0, sizeof(double) * (size_t)B * NP * MP));
+                HIP_TRY(hipMemset(c->ukf.DZ, 0, sizeof(double) * (size_t)B * NP * MP));
+                HIP_TRY(hipMemset(c->ukf.Tc, 0, sizeof(double) * (size_t)B * NP * NP));
+                HIP_TRY(hipMemset(c->ukf.K, 0, sizeof(double) * (size_t)B * NP * NP));
+        }
+#endif
         // P = Identity * KP_ROBOT_POSE on the 3 pose entries
         const double p0 = (double)KP_ROBOT_POSE;
         std::vector<double> blk((size_t)3 * NP, 0.0);
