@@ -8,9 +8,24 @@ namespace aslam
 /// The two rows of T_i applied to a column (m0, m1, m2, ma, mb) of values indexed by (p0, p1, p2, l_a, l_b):
 ///   FWD:  T_i = rows of H (updateH, ekf.cpp:117-134):   [h0 h1 0 -h0 -h1], [h2 h3 -1 -h2 -h3]       (c = hc[0..3])
 ///   else: T_i = rows of H^-1:                            [1 0 -g1 -g0 -g1], [0 1 -g3 -g2 -g3]         (c = hc[4..7])
-template <bool FWD>
-__device__ __forceinline__ void lm_rows(const double *c, double m0, double m1, double m2, double ma, double mb, double &w0, double &w1)
+struct LmCoef
 {
+        double c[4];
+};
+/// coefficients of landmark i: coefficient-major in LDS (sH[k][i], k = 0..3 the rows of H, 4..7 of H^-1), so that lanes running over landmarks read
+/// consecutive words (round 4; landmark-major before: a 64-byte stride, sixteen lanes on a bank)
+template <bool FWD> __device__ __forceinline__ LmCoef lm_coef(const double *sH, int nlm, int i)
+{
+        LmCoef r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+                r.c[k] = sH[((FWD ? 0 : 4) + k) * nlm + i];
+        return r;
+}
+template <bool FWD>
+__device__ __forceinline__ void lm_rows(const LmCoef &cc, double m0, double m1, double m2, double ma, double mb, double &w0, double &w1)
+{
+        const double *c = cc.c;
         if (FWD)
         {
                 const double d0 = m0 - ma, d1 = m1 - mb;
@@ -27,62 +42,91 @@ __device__ __forceinline__ void lm_rows(const double *c, double m0, double m1, d
 
 /// P <- T P T^T on the symmetric P held as lower tiles in LDS, T = H (FWD) or H^-1.  T is the identity on the pose and
 /// couples landmark i only to the pose and to itself, so the 2x2 block (i, j) of the result needs the pose block, the pose
-/// columns of landmarks i and j and its own old value: after a side copy of the pose columns (`pose`: [n][3], LDS)
-/// every block is transformed in place by one thread, in one pass: W = T_i M (2 x 5, column by column), block = W T_j^T.
+/// columns of landmarks i and j and its own old value: after a side copy of the pose columns (`pose`: column-major [3][ps], LDS)
+/// every block is transformed in place, in one pass: W = T_i M (2 x 5, column by column), block = W T_j^T.
+/// A thread walks up to CONG_SEG blocks j = j0 .. of ONE landmark row i (round 4): what depends on i alone -- the coefficients, the pose
+/// columns of its two rows, the three pose columns of W, the row part of the tile addresses -- is formed once per thread, and the thread
+/// of a row's first segment also stores the landmark-pose block (it is those three columns of W).  One block per thread before: ~ 300
+/// instructions per block, half of them index arithmetic, three passes of the workgroup at 64 landmarks and 9 k cycles per call, bound by
+/// instruction issue (a 4x4-entry ownership was no better: fewer instructions, fewer busy waves; LDS bank conflicts were not it either:
+/// profiles/r04_experiments.md section 12).  Rows come in groups of CONG_SEG (group a: a + 1 segments per row), which makes the decode
+/// of (i, j0) from the flat index one square root.  Every block is formed by the same expressions as before, bit for bit.
 /// Ends with a barrier.
-template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt, double *pose, const double *sH, int n, int nl, int tid)
+constexpr int CONG_SEG = 3;
+template <bool FWD> __device__ __forceinline__ void congruence_tiles(double *Lt, double *pose, const double *sH, int nlm, int n, int nl, int tid)
 {
+        const int ps = 2 * nlm; // (= NP >= n)
         for (int idx = tid; idx < 3 * n; idx += SMALL_WG)
         {
-                const int r = idx / 3, k = idx - 3 * r;
-                pose[idx] = sym_get(Lt, r, k);
+                const int k = idx / n, r = idx - k * n;
+                pose[k * ps + r] = sym_get(Lt, r, k);
         }
         __syncthreads();
-        const int npair = nl * (nl + 1) / 2;
-        for (int w = tid; w < npair + nl; w += SMALL_WG)
+        const double *pq0 = pose, *pq1 = pose + ps, *pq2 = pose + 2 * ps; // pqk[r] = P(r, k)
+        constexpr int SEG = CONG_SEG;
+        const int ng = (nl + SEG - 1) / SEG;
+        const int nseg = SEG * ng * (ng + 1) / 2;
+        for (int w = tid; w < nseg; w += SMALL_WG)
         {
-                if (w < nl)
+                // group a: SEG a (a + 1) / 2 <= w
+                int a = (int)((sqrtf(1.0f + (8.0f / (float)SEG) * (float)w) - 1.0f) * 0.5f);
+                while (SEG * (a + 1) * (a + 2) / 2 <= w)
+                        ++a;
+                while (SEG * a * (a + 1) / 2 > w)
+                        --a;
+                const int rem = w - SEG * a * (a + 1) / 2; // < SEG (a + 1)
+                int bq = 0;
+#pragma unroll
+                for (int u = 1; u < SEG; ++u)
+                        bq += (rem >= u * (a + 1)) ? 1 : 0;
+                const int sg = rem - bq * (a + 1);
+                const int i = SEG * a + bq;
+                if (i >= nl)
+                        continue;
+                const int j0 = SEG * sg;
+                const int ra = 3 + 2 * i;
+                const LmCoef ci = lm_coef<FWD>(sH, nlm, i);
+                // columns of M = old P over rows (p0, p1, p2, a_i, b_i); columns (p0, p1, p2, a_j, b_j)
+                double W0[5], W1[5];
+                lm_rows<FWD>(ci, pq0[0], pq0[1], pq0[2], pq0[ra], pq0[ra + 1], W0[0], W1[0]);
+                lm_rows<FWD>(ci, pq1[0], pq1[1], pq1[2], pq1[ra], pq1[ra + 1], W0[1], W1[1]);
+                lm_rows<FWD>(ci, pq2[0], pq2[1], pq2[2], pq2[ra], pq2[ra + 1], W0[2], W1[2]);
+                // tile_elem(r, c) = Lt + rowp(r) + colp(c) for c <= r
+                double *const row_a = Lt + tile_index(ra >> 4, 0) * TSZ + (ra & 15) * TLD;
+                double *const row_b = Lt + tile_index((ra + 1) >> 4, 0) * TSZ + ((ra + 1) & 15) * TLD;
+                if (sg == 0)
                 {
                         // landmark-pose block: rows 3+2i, 4+2i; columns 0..2 = the first three columns of W
-                        const int ra = 3 + 2 * w;
-                        const double *ci = sH + 8 * w + (FWD ? 0 : 4);
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
                         {
-                                double w0, w1;
-                                lm_rows<FWD>(ci, pose[k], pose[3 + k], pose[6 + k], pose[3 * ra + k], pose[3 * (ra + 1) + k], w0, w1);
-                                *tile_elem(Lt, ra, k) = w0;
-                                *tile_elem(Lt, ra + 1, k) = w1;
+                                row_a[k] = W0[k];
+                                row_b[k] = W1[k];
                         }
-                        continue;
                 }
-                const int q = w - nl;
-                int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-                while ((i + 1) * (i + 2) / 2 <= q)
-                        ++i;
-                while (i * (i + 1) / 2 > q)
-                        --i;
-                const int j = q - i * (i + 1) / 2; // j <= i
-                const int ra = 3 + 2 * i, ca = 3 + 2 * j;
-                const double *ci = sH + 8 * i + (FWD ? 0 : 4), *cj = sH + 8 * j + (FWD ? 0 : 4);
-                // columns of M = old P over rows (p0, p1, p2, a_i, b_i); columns (p0, p1, p2, a_j, b_j)
-                double W0[5], W1[5];
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                        lm_rows<FWD>(ci, pose[k], pose[3 + k], pose[6 + k], pose[3 * ra + k], pose[3 * (ra + 1) + k], W0[k], W1[k]);
-                double *e_aa = tile_elem(Lt, ra, ca), *e_ba = tile_elem(Lt, ra + 1, ca), *e_bb = tile_elem(Lt, ra + 1, ca + 1);
-                double *e_ab = (i == j) ? e_ba : tile_elem(Lt, ra, ca + 1);
-                lm_rows<FWD>(ci, pose[3 * ca], pose[3 * ca + 1], pose[3 * ca + 2], *e_aa, *e_ba, W0[3], W1[3]);
-                lm_rows<FWD>(ci, pose[3 * (ca + 1)], pose[3 * (ca + 1) + 1], pose[3 * (ca + 1) + 2], *e_ab, *e_bb, W0[4], W1[4]);
-                // block = W T_j^T: the rows of T_j applied to the rows of W
-                double o00, o01, o10, o11;
-                lm_rows<FWD>(cj, W0[0], W0[1], W0[2], W0[3], W0[4], o00, o01);
-                lm_rows<FWD>(cj, W1[0], W1[1], W1[2], W1[3], W1[4], o10, o11);
-                *e_aa = o00;
-                *e_ba = o10;
-                *e_bb = o11;
-                if (i != j)
-                        *e_ab = o01; // the diagonal block is symmetric: lower entries only
+                for (int u = 0; u < SEG; ++u)
+                {
+                        const int j = j0 + u;
+                        if (j > i)
+                                break;
+                        const int ca = 3 + 2 * j;
+                        const LmCoef cj = lm_coef<FWD>(sH, nlm, j);
+                        const int col_a = (ca >> 4) * TSZ + (ca & 15), col_b = ((ca + 1) >> 4) * TSZ + ((ca + 1) & 15);
+                        double *e_aa = row_a + col_a, *e_ba = row_b + col_a, *e_bb = row_b + col_b;
+                        double *e_ab = (i == j) ? e_ba : row_a + col_b;
+                        lm_rows<FWD>(ci, pq0[ca], pq1[ca], pq2[ca], *e_aa, *e_ba, W0[3], W1[3]);
+                        lm_rows<FWD>(ci, pq0[ca + 1], pq1[ca + 1], pq2[ca + 1], *e_ab, *e_bb, W0[4], W1[4]);
+                        // block = W T_j^T: the rows of T_j applied to the rows of W
+                        double o00, o01, o10, o11;
+                        lm_rows<FWD>(cj, W0[0], W0[1], W0[2], W0[3], W0[4], o00, o01);
+                        lm_rows<FWD>(cj, W1[0], W1[1], W1[2], W1[3], W1[4], o10, o11);
+                        *e_aa = o00;
+                        *e_ba = o10;
+                        *e_bb = o11;
+                        if (i != j)
+                                *e_ab = o01; // the diagonal block is symmetric: lower entries only
+                }
         }
         __syncthreads();
 }
@@ -92,7 +136,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                                                               int32_t *dims_out, StepArgs sa)
 {
         typedef SmallLayout<NT> LY;
-        constexpr int NP = LY::NP;
+        constexpr int NP = LY::NP, NLM = NP / 2;
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
         const SmallLds L = small_carve<NT>(smem);
         double *const Lt = L.Lt, *const Dinv = L.Dinv, *const sX = L.sX, *const sZ = L.sZ, *const sY = L.sY, *const sU = L.sU,
@@ -175,15 +219,15 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                         const double h10 = -(-ly + x1) / (double)hyp;
                         const double h11 = (-lx + x0) / (double)hyp;
                         const double det = h00 * h11 - h01 * h10;
-                        double *hc = sH + 8 * i;
+                        double *hc = sH + i; // coefficient-major: hc[k * NLM] (lm_coef)
                         hc[0] = h00;
-                        hc[1] = h01;
-                        hc[2] = h10;
-                        hc[3] = h11;
-                        hc[4] = h11 / det;
-                        hc[5] = -h01 / det;
-                        hc[6] = -h10 / det;
-                        hc[7] = h00 / det;
+                        hc[NLM] = h01;
+                        hc[2 * NLM] = h10;
+                        hc[3 * NLM] = h11;
+                        hc[4 * NLM] = h11 / det;
+                        hc[5 * NLM] = -h01 / det;
+                        hc[6 * NLM] = -h10 / det;
+                        hc[7 * NLM] = h00 / det;
                         // measurementFunction, common.h:78-90
                         const double hr = sqrt(ddx * ddx + ddy * ddy);
                         const double hb = atan2(ddy, ddx) - sX[2];
@@ -222,7 +266,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 }
                 ASLAM_STAMP(1);
                 // Pt = H P H^T, in place on the tiles (the inverted-diagonal-tile area is free until the solve: side copy of the pose columns)
-                congruence_tiles<true>(Lt, Dinv, sH, n, nl, tid);
+                congruence_tiles<true>(Lt, Dinv, sH, NLM, n, nl, tid);
                 ASLAM_STAMP(2);
                 ASLAM_STAMP(3);
                 ASLAM_STAMP(4);
@@ -241,10 +285,10 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                         const double u0 = sU[0], u1 = sU[1], u2 = sU[2];
                         for (int i = tid; i < nl; i += SMALL_WG)
                         {
-                                const double *hc = sH + 8 * i;
+                                const double *hc = sH + i;
                                 const double ua = sU[3 + 2 * i], ub = sU[4 + 2 * i] + u2;
-                                sX[3 + 2 * i] += u0 - (hc[4] * ua + hc[5] * ub);
-                                sX[4 + 2 * i] += u1 - (hc[6] * ua + hc[7] * ub);
+                                sX[3 + 2 * i] += u0 - (hc[4 * NLM] * ua + hc[5 * NLM] * ub);
+                                sX[4 + 2 * i] += u1 - (hc[6 * NLM] * ua + hc[7 * NLM] * ub);
                         }
                         __syncthreads();
                         if (tid < 3)
@@ -252,7 +296,7 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 }
                 ASLAM_STAMP(7);
                 // P = (I - K H) P = H^-1 (r Kt) H^-T (ekf.cpp:310), in place on the tiles
-                congruence_tiles<false>(Lt, Dinv, sH, n, nl, tid);
+                congruence_tiles<false>(Lt, Dinv, sH, NLM, n, nl, tid);
                 ASLAM_STAMP(8);
                 ASLAM_STAMP(9);
                 if (MODE == MODE_REPLAY)

@@ -133,7 +133,7 @@ template <int NT> struct SmallLayout
         static constexpr int oZ = oX + NP;
         static constexpr int oY = oZ + NP;
         static constexpr int oU = oY + NP;
-        static constexpr int oH = oU + NP;           // per landmark: h00 h01 h10 h11 e00 e01 e10 e11
+        static constexpr int oH = oU + NP;           // [8][NP/2], coefficient-major: h00 h01 h10 h11 (rows of H) e00 e01 e10 e11 (of H^-1) per landmark (ekf_small.h lm_coef)
         static constexpr int oTv = oH + (NP / 2) * 8; // scratch vector of the EKF's inverse-based update
         static constexpr int oEnd = oTv + NP;
         // then floats / ints
@@ -212,11 +212,78 @@ __device__ __forceinline__ double rsqrt_newton(double x)
 }
 
 /// Cholesky factor of the 16x16 diagonal tile `T` (LDS, lower triangle valid) in place, and the inverse of that factor to `Ti`;
-/// returns false on a non-positive pivot.  Tuned for the 32-cycle dependent-f64 latency of gfx950: pivots through rsqrt_newton, and
-/// the inverse is built INSIDE the pivot loop (outer-product form): lane c carries column c of L^-1 as running sums
-/// s[i]; once column j of L is final, x_j = s[j] / L(j,j) and s[i] -= L(i,j) x_j use the very multipliers
-/// L(i,j) the factorisation has just broadcast, and none of that work sits on the pivot dependency chain.
-/// One wave (all 64 lanes run; lanes 16-63 mirror rows/columns 0-15).
+/// returns false on a non-positive pivot.  One wave; this is the serial spine of every fused factorisation of the single-CU kernels
+/// (nine tiles per callback at n = 131).  Outer-product form with the inverse built INSIDE the pivot loop: lane i (& 15; the four rows of
+/// sixteen lanes mirror each other) carries row i of the tile in a[] and column i of L^-1 as running sums in s[]; once column j of L is
+/// final, x_j = s[j] / L(j,j), and a[c] -= L(i,j) L(c,j), s[c] -= L(c,j) x_j use the same multiplier L(c,j).
+/// Round 4: that multiplier reaches the lanes through the DPP operand of the fmac itself (row_newbcast:c -- lane c of each row of sixteen,
+/// the one DPP control gfx90a+ has for 64-bit operations; every row holds the same column, so the row-local broadcast is the right one):
+/// ONE instruction per update instead of two v_readlane_b32, a wait state and the fma.  The function is issue-bound, not latency-bound --
+/// measured on one wave (tools/ubench/fd_bench.hip, cycles per tile): 5 140 with v_readlane (4 340 in the loop; 2 070 with the pivot
+/// chain alone; halving the fmas or shortening the chain from nine to six dependent operations changed nothing) against 4 025 with DPP.
+/// The pivot chain is still hand-scheduled: hipcc sinks the updates into lazy dot-product chains in front of every pivot otherwise; column
+/// j's updates are issued eagerly, the one the next pivot needs first, the rest between the steps of the next pivot's rsqrt chain.
+#define ASLAM_DPP_FMAC(acc, bsrc, other, c)                                                                            \
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:" #c " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(other))
+/// a[C] -= L(C, j) lij, s[C] -= L(C, j) xj for one column C (compile-time: the DPP control is an immediate)
+template <int C> __device__ __forceinline__ void factor_diag_update(double (&a)[16], double (&s)[16], const double &lij, const double &xj)
+{
+        if constexpr (C < 16)
+        {
+#define ASLAM_CASE(cc)                                                                                                 \
+        if constexpr (C == cc)                                                                                         \
+        {                                                                                                              \
+                ASLAM_DPP_FMAC(a[cc], lij, lij, cc);                                                                   \
+                ASLAM_DPP_FMAC(s[cc], lij, xj, cc);                                                                    \
+        }
+                ASLAM_CASE(1) ASLAM_CASE(2) ASLAM_CASE(3) ASLAM_CASE(4) ASLAM_CASE(5) ASLAM_CASE(6) ASLAM_CASE(7) ASLAM_CASE(8) ASLAM_CASE(9)
+                ASLAM_CASE(10) ASLAM_CASE(11) ASLAM_CASE(12) ASLAM_CASE(13) ASLAM_CASE(14) ASLAM_CASE(15)
+#undef ASLAM_CASE
+        }
+}
+template <int J> __device__ __forceinline__ void factor_diag_column(double (&a)[16], double (&s)[16], double &inv, bool &ok)
+{
+        double lij = a[J] * inv; // L(i,J) for i >= J
+        double xj = s[J] * inv;  // (L^-1)(J, lane)
+        a[J] = lij;
+        s[J] = xj;
+        asm volatile("s_nop 1" : "+v"(lij), "+v"(xj)); // a VALU result read through DPP: two wait states (inline assembly is not covered by the hazard recogniser)
+        double d = 1.0, y = 1.0;
+        factor_diag_update<J + 1>(a, s, lij, xj);
+        if constexpr (J + 1 < 16)
+        {
+                d = readlane_f64(a[J + 1], J + 1);
+                ok = ok && (d > 0.0);
+                y = __builtin_amdgcn_rsq(d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double t = d * y;
+        factor_diag_update<J + 2>(a, s, lij, xj);
+        factor_diag_update<J + 3>(a, s, lij, xj);
+        factor_diag_update<J + 4>(a, s, lij, xj);
+        __builtin_amdgcn_sched_barrier(0);
+        const double e = fma(-t, y, 1.0);
+        factor_diag_update<J + 5>(a, s, lij, xj);
+        factor_diag_update<J + 6>(a, s, lij, xj);
+        factor_diag_update<J + 7>(a, s, lij, xj);
+        __builtin_amdgcn_sched_barrier(0);
+        const double ye = y * e, pp = fma(e, 0.375, 0.5); // third-order step of rsqrt_newton
+        factor_diag_update<J + 8>(a, s, lij, xj);
+        factor_diag_update<J + 9>(a, s, lij, xj);
+        factor_diag_update<J + 10>(a, s, lij, xj);
+        __builtin_amdgcn_sched_barrier(0);
+        const double invn = fma(ye, pp, y);
+        factor_diag_update<J + 11>(a, s, lij, xj);
+        factor_diag_update<J + 12>(a, s, lij, xj);
+        factor_diag_update<J + 13>(a, s, lij, xj);
+        factor_diag_update<J + 14>(a, s, lij, xj);
+        factor_diag_update<J + 15>(a, s, lij, xj);
+        __builtin_amdgcn_sched_barrier(0);
+        inv = readfirstlane_f64(invn);
+        if constexpr (J + 1 < 16)
+                factor_diag_column<J + 1>(a, s, inv, ok);
+}
+/// (all 64 lanes must be active: the DPP broadcasts are per row of sixteen lanes, and lanes 16-63 mirror rows/columns 0-15)
 __device__ __forceinline__ bool factor_diag_tile_fast(double *T, double *Ti, int lane)
 {
         double a[16], s[16];
@@ -227,64 +294,10 @@ __device__ __forceinline__ bool factor_diag_tile_fast(double *T, double *Ti, int
                 a[c] = T[row * TLD + c];
                 s[c] = (row == c) ? 1.0 : 0.0;
         }
-        // Hand-scheduled: left to itself hipcc sinks the rank-1 updates into lazy dot-product chains (one dependent
-        // 32-cycle v_fma_f64 per earlier column in front of every pivot) and spills the broadcast multipliers.  Here
-        // column j's updates are issued eagerly, the critical one (row/column j+1) first, and the remaining ones fill
-        // the latency gaps of the NEXT pivot's rsqrt chain; sched_barrier pins that order.
-#define ASLAM_UPD(c)                                                                                                   \
-        if ((c) < 16)                                                                                                  \
-        {                                                                                                              \
-                const double lc_ = readlane_f64(lij, ((c) < 16) ? (c) : 15);                                           \
-                a[((c) < 16) ? (c) : 15] = fma(-lij, lc_, a[((c) < 16) ? (c) : 15]);                                   \
-                s[((c) < 16) ? (c) : 15] = fma(-lc_, xj, s[((c) < 16) ? (c) : 15]);                                    \
-                asm volatile("" : "+v"(a[((c) < 16) ? (c) : 15]), "+v"(s[((c) < 16) ? (c) : 15])); /* no sinking */   \
-        }
         const double d0 = readlane_f64(a[0], 0);
         bool ok = d0 > 0.0;
         double inv = readfirstlane_f64(rsqrt_newton(d0));
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-        {
-                const double lij = a[j] * inv; // L(i,j) for i >= j
-                const double xj = s[j] * inv;  // (L^-1)(j, lane)
-                a[j] = lij;
-                s[j] = xj;
-                double d = 1.0, y = 1.0, t = 0.0, e = 0.0, ye = 0.0, pp = 0.0, invn = 1.0;
-                __builtin_amdgcn_sched_barrier(0);
-                ASLAM_UPD(j + 1);
-                if (j + 1 < 16)
-                {
-                        d = readlane_f64(a[(j + 1 < 16) ? j + 1 : 15], (j + 1 < 16) ? j + 1 : 15);
-                        ok = ok && (d > 0.0);
-                        y = __builtin_amdgcn_rsq(d);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                t = d * y;
-                ASLAM_UPD(j + 2);
-                ASLAM_UPD(j + 3);
-                ASLAM_UPD(j + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                e = fma(-t, y, 1.0);
-                ASLAM_UPD(j + 5);
-                ASLAM_UPD(j + 6);
-                ASLAM_UPD(j + 7);
-                __builtin_amdgcn_sched_barrier(0);
-                ye = y * e;
-                pp = fma(e, 0.375, 0.5);
-                ASLAM_UPD(j + 8);
-                ASLAM_UPD(j + 9);
-                ASLAM_UPD(j + 10);
-                __builtin_amdgcn_sched_barrier(0);
-                invn = fma(ye, pp, y);
-                ASLAM_UPD(j + 11);
-                ASLAM_UPD(j + 12);
-                ASLAM_UPD(j + 13);
-                ASLAM_UPD(j + 14);
-                ASLAM_UPD(j + 15);
-                __builtin_amdgcn_sched_barrier(0);
-                inv = readfirstlane_f64(invn);
-        }
-#undef ASLAM_UPD
+        factor_diag_column<0>(a, s, inv, ok);
         if (lane < 16)
         {
 #pragma unroll
@@ -296,6 +309,7 @@ __device__ __forceinline__ bool factor_diag_tile_fast(double *T, double *Ti, int
         }
         return ok;
 }
+#undef ASLAM_DPP_FMAC
 
 /// Load the 16 rows [16 rb, 16 rb + 16) of Src (row-major, stride NP) into MFMA accumulator layout, transposed:
 /// acc[cb][r] of lane l = Src[16 rb + (l&15)][16 cb + (l>>4) + 4 r].
@@ -1110,6 +1124,15 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         unsigned long long fe_last = __builtin_amdgcn_s_memtime();
 #endif
         // ================= message intake
+        // The observation row of this callback is fetched next to thread 0's scalars (one global latency instead of two; the row has max_obs entries
+        // whatever tr_nobs says, and it is only kept when the message is new).
+        const float *src = d.tr_obs + ((size_t)b * d.T + t) * d.max_obs * 2;
+        float ob0r = 0.0f, ob0b = 0.0f;
+        if (tid < min(d.max_obs, OBS_CAP))
+        {
+                ob0r = src[2 * tid];
+                ob0b = src[2 * tid + 1];
+        }
         if (tid == 0)
         {
                 const size_t o = (size_t)b * d.T + t;
@@ -1135,8 +1158,12 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         if (sm.obs_new)
         {
                 // cbSensorLandmark, ekf.cpp:102-114
-                const float *src = d.tr_obs + ((size_t)b * d.T + t) * d.max_obs * 2;
-                for (int j = tid; j < sm.nobs; j += SMALL_WG)
+                if (tid < sm.nobs)
+                {
+                        sSr[tid] = ob0r;
+                        sSb[tid] = ob0b;
+                }
+                for (int j = tid + SMALL_WG; j < sm.nobs; j += SMALL_WG)
                 {
                         sSr[j] = src[2 * j];
                         sSb[j] = src[2 * j + 1];
@@ -1181,19 +1208,46 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         {
                 L.sLm[2 * k] = (float)sX[3 + 2 * k]; // Point(const float &, const float &), structures.h:50
                 L.sLm[2 * k + 1] = (float)sX[4 + 2 * k];
+                sNew[k] = -1; // last observation associated with landmark k
+        }
+        // Update A, ekf.cpp:206-212 (the UKF node has no A), and slam()'s binary32 arguments: they depend on the odom message alone, so the last two waves
+        // form them here -- one the cosines, one the sines, the two angles on two lanes side by side -- instead of thread 0 one libm call after the other
+        // behind the wait-list walk (round 4: ~ 3 k cycles of a callback's 150 k at n = 131)
+        if (tid >= SMALL_WG - 128)
+        {
+                const int l = tid & 63;
+                const bool sines = tid < SMALL_WG - 64; // (wave-uniform)
+                if (IS_EKF && sm.tvx != 0.0 && sm.twz != 0.0)
+                {
+                        const float delta_theta = (float)(sm.twz * (double)sm.dt);
+                        const float rr = (float)(sm.tvx / sm.twz);
+                        const double ang = (l & 1) ? sZ[2] + (double)delta_theta : sZ[2];
+                        const double v = sines ? sin(ang) : cos(ang);
+                        const double v1 = __shfl_down(v, 1);
+                        if (l == 0)
+                                (sines ? sm.a10 : sm.a00) = (double)rr * (-v + v1);
+                }
+                if (l == 0 && !sines)
+                {
+                        sm.vx = (float)sm.tvx; // slam(const float &vx, ...), ekf.cpp:94,293
+                        sm.az = (float)sm.twz;
+                }
         }
         __syncthreads();
-        FE_STAMP(6); // toPoint + landmark narrowing
-        // nearest mapped landmark of every observation (ekf.cpp:159-173).  Four threads per observation scan the landmarks
-        // k = c, c+4, c+8, ... each (adjacent LDS words across the four: no bank conflicts), in index order with the
+        FE_STAMP(6); // toPoint + landmark narrowing + A
+        // nearest mapped landmark of every observation (ekf.cpp:159-173).  Eight lanes per observation scan the landmarks
+        // k = c, c+8, c+16, ... each (adjacent LDS words across the eight: no bank conflicts), in index order with the
         // reference's strict `dist < mindist`.  sqrtf is correctly rounded, hence monotonic: a candidate whose squared
         // distance is not below the squared distance of the current best cannot have a smaller distance, so the root is only
         // taken for the few that pass that test -- the comparison that decides is still the reference's, on the rooted values.
-        // The four partial results are then combined (smallest distance, smallest index among equals = first in index order),
-        // so ties, infinities and NaNs resolve exactly as in the sequential scan.
-        for (int idx = tid; idx < 4 * sm.sn; idx += SMALL_WG)
+        // The eight partial results are then combined by three exchanges inside the group (smallest distance, smallest index among
+        // equals = first in index order; lane 0 of the group holds landmark 0's starting value and keeps it unless something is
+        // strictly smaller -- also when it is an infinity or a NaN), so ties, infinities and NaNs resolve exactly as in the sequential scan.
+        // (Round 4: four threads per observation and a pass through LDS before: 8.3 k cycles at n = 131.)
+        constexpr int SCAN_LANES = 8;
+        for (int idx = tid; idx < SCAN_LANES * sm.sn; idx += SMALL_WG)
         {
-                const int j = idx >> 2, c = idx & 3;
+                const int j = idx / SCAN_LANES, c = idx % SCAN_LANES;
                 const float ox = sPx[j], oy = sPy[j];
                 float bd = __builtin_inff(), bd2 = __builtin_inff();
                 int bk = -1;
@@ -1209,59 +1263,60 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         bd2 = dx * dx + dy * dy;
                         bd = sqrtf(bd2);
                         bk = 0;
-                        k = 4;
+                        k = SCAN_LANES;
                 }
-#pragma unroll 4
-                for (; k < nl; k += 4)
+                constexpr int CH = 8; // candidates fetched together: the LDS reads of a chunk are in flight at once (one at a time: ~ 250 cycles per candidate)
+                for (; k < nl; k += SCAN_LANES * CH)
                 {
-                        const float2 p = lm[k];
-                        const float dx = ox - p.x, dy = oy - p.y;
-                        const float d2 = dx * dx + dy * dy;
-                        if (d2 < bd2)
+                        float2 p[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                                p[u] = lm[min(k + u * SCAN_LANES, nl - 1)];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
                         {
-                                const float dd = sqrtf(d2);
-                                if (dd < bd)
+                                const int kk = k + u * SCAN_LANES;
+                                const float dx = ox - p[u].x, dy = oy - p[u].y;
+                                const float d2 = dx * dx + dy * dy;
+                                if (kk < nl && d2 < bd2)
                                 {
-                                        bd = dd;
-                                        bd2 = d2;
-                                        bk = k;
+                                        const float dd = sqrtf(d2);
+                                        if (dd < bd)
+                                        {
+                                                bd = dd;
+                                                bd2 = d2;
+                                                bk = kk;
+                                        }
                                 }
                         }
                 }
-                L.sPd[idx] = bd;
-                L.sPi[idx] = bk;
-        }
-        for (int k = tid; k < nl; k += SMALL_WG)
-                sNew[k] = -1; // last observation associated with landmark k
-        FE_STAMP(7); // scan
-        __syncthreads();
-        for (int j = tid; j < sm.sn; j += SMALL_WG)
-        {
-                float bd = L.sPd[4 * j];
-                int bk = L.sPi[4 * j];
 #pragma unroll
-                for (int c = 1; c < 4; ++c)
+                for (int off = 1; off < SCAN_LANES; off <<= 1)
                 {
-                        const float od = L.sPd[4 * j + c];
-                        const int ok = L.sPi[4 * j + c];
+                        const float od = __shfl_xor(bd, off);
+                        const int ok = __shfl_xor(bk, off);
                         if (ok >= 0 && (od < bd || (od == bd && ok < bk)))
                         {
                                 bd = od;
                                 bk = ok;
                         }
                 }
-                if (nl == 0)
+                if (c == 0)
                 {
-                        bd = __builtin_inff();
-                        bk = 0;
+                        if (nl == 0)
+                        {
+                                bd = __builtin_inff();
+                                bk = 0;
+                        }
+                        sMd[j] = bd;
+                        sCid[j] = 2 * bk;
+                        if (n0 != 3 && bd < MIN_DIST_THRESH)
+                                atomicMax(&sNew[bk], j); // observations are walked in order: the last one wins (ekf.cpp:175-181)
+                        else
+                                sm.any_miss = 1;
                 }
-                sMd[j] = bd;
-                sCid[j] = 2 * bk;
-                if (n0 != 3 && bd < MIN_DIST_THRESH)
-                        atomicMax(&sNew[bk], j); // observations are walked in order: the last one wins (ekf.cpp:175-181)
-                else
-                        sm.any_miss = 1;
         }
+        FE_STAMP(7); // scan + combine
         __syncthreads();
         // associated observations: Z(3 + corr_id) = range, Z(4 + corr_id) = bearing
         for (int j = tid; j < sm.sn; j += SMALL_WG)
@@ -1432,19 +1487,6 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 }
         }
         FE_STAMP(9); // wait-list walk
-        if (tid == 0)
-        {
-                // Update A, ekf.cpp:206-212 (the UKF node has no A)
-                if (IS_EKF && sm.tvx != 0.0 && sm.twz != 0.0)
-                {
-                        const float delta_theta = (float)(sm.twz * (double)sm.dt);
-                        const float rr = (float)(sm.tvx / sm.twz);
-                        sm.a00 = (double)rr * (-cos(sZ[2]) + cos(sZ[2] + (double)delta_theta));
-                        sm.a10 = (double)rr * (-sin(sZ[2]) + sin(sZ[2] + (double)delta_theta));
-                }
-                sm.vx = (float)sm.tvx; // slam(const float &vx, ...), ekf.cpp:94,293
-                sm.az = (float)sm.twz;
-        }
         __syncthreads();
         FE_STAMP(10); // A
         if (sm.grew)
