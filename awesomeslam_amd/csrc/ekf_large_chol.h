@@ -47,9 +47,55 @@ __device__ __forceinline__ d4 xyt(const double *X, const double *Y, d4 acc, doub
 
 /// Cholesky factor of the 16x16 diagonal tile `T` (binary64 in LDS, lower triangle valid) in place and the inverse of the factor -> `Ti`,
 /// computed in BINARY32: the data of this path is binary32 (S, L and every product), and the 16 dependent pivot steps are the serial spine of
-/// the diagonal blocks -- a dependent v_fma_f64 takes 32 cycles on gfx950 (7.6 k cycles per tile for factor_diag_tile_fast), a v_fma_f32 a
-/// quarter of that.  One wave; lane i < 16 owns row i (lanes 16-63 mirror), multipliers travel through v_readlane, the inverse rides on the
-/// same broadcasts (outer-product form, as factor_diag_tile_fast).  Returns false on a non-positive pivot.
+/// the diagonal blocks.  One wave, all 64 lanes active; lane i < 16 owns row i (lanes 16-63 mirror), the inverse rides on the same multipliers
+/// (outer-product form, as factor_diag_tile_fast), and like there (round 4) the multiplier L(c, j) reaches the lanes through the DPP operand of
+/// the fmac (row_newbcast:c) instead of a v_readlane into an SGPR per update.  Returns false on a non-positive pivot.
+#define ASLAM_DPP_FMAC32(acc, bsrc, other, c)                                                                          \
+        asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:" #c " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(other))
+template <int C> __device__ __forceinline__ void factor_diag_update_f32(float (&a)[16], float (&s)[16], const float &lij, const float &xj)
+{
+        if constexpr (C < 16)
+        {
+#define ASLAM_CASE(cc)                                                                                                 \
+        if constexpr (C == cc)                                                                                         \
+        {                                                                                                              \
+                ASLAM_DPP_FMAC32(a[cc], lij, lij, cc);                                                                 \
+                ASLAM_DPP_FMAC32(s[cc], lij, xj, cc);                                                                  \
+        }
+                ASLAM_CASE(1) ASLAM_CASE(2) ASLAM_CASE(3) ASLAM_CASE(4) ASLAM_CASE(5) ASLAM_CASE(6) ASLAM_CASE(7) ASLAM_CASE(8) ASLAM_CASE(9)
+                ASLAM_CASE(10) ASLAM_CASE(11) ASLAM_CASE(12) ASLAM_CASE(13) ASLAM_CASE(14) ASLAM_CASE(15)
+#undef ASLAM_CASE
+        }
+}
+template <int J> __device__ __forceinline__ void factor_diag_column_f32(float (&a)[16], float (&s)[16], bool &ok)
+{
+        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[J]), J));
+        ok = ok && (d > 0.f);
+        const float y = __builtin_amdgcn_rsqf(d);
+        const float inv = y * fmaf(-0.5f * d * y, y, 1.5f); // one Newton step on the hardware seed
+        float lij = a[J] * inv;                             // L(i, J) for i >= J
+        float xj = s[J] * inv;                              // (L^-1)(J, lane)
+        a[J] = lij;
+        s[J] = xj;
+        asm volatile("s_nop 1" : "+v"(lij), "+v"(xj)); // a VALU result read through DPP: two wait states
+        factor_diag_update_f32<J + 1>(a, s, lij, xj);
+        factor_diag_update_f32<J + 2>(a, s, lij, xj);
+        factor_diag_update_f32<J + 3>(a, s, lij, xj);
+        factor_diag_update_f32<J + 4>(a, s, lij, xj);
+        factor_diag_update_f32<J + 5>(a, s, lij, xj);
+        factor_diag_update_f32<J + 6>(a, s, lij, xj);
+        factor_diag_update_f32<J + 7>(a, s, lij, xj);
+        factor_diag_update_f32<J + 8>(a, s, lij, xj);
+        factor_diag_update_f32<J + 9>(a, s, lij, xj);
+        factor_diag_update_f32<J + 10>(a, s, lij, xj);
+        factor_diag_update_f32<J + 11>(a, s, lij, xj);
+        factor_diag_update_f32<J + 12>(a, s, lij, xj);
+        factor_diag_update_f32<J + 13>(a, s, lij, xj);
+        factor_diag_update_f32<J + 14>(a, s, lij, xj);
+        factor_diag_update_f32<J + 15>(a, s, lij, xj);
+        if constexpr (J + 1 < 16)
+                factor_diag_column_f32<J + 1>(a, s, ok);
+}
 __device__ __forceinline__ bool factor_diag_tile_f32(double *T, double *Ti, int lane)
 {
         float a[16], s[16];
@@ -60,27 +106,8 @@ __device__ __forceinline__ bool factor_diag_tile_f32(double *T, double *Ti, int 
                 a[c] = (float)T[row * TLD + c];
                 s[c] = (row == c) ? 1.f : 0.f;
         }
-        auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
         bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-        {
-                const float d = bcast(a[j], j);
-                ok = ok && (d > 0.f);
-                const float y = __builtin_amdgcn_rsqf(d);
-                const float inv = y * fmaf(-0.5f * d * y, y, 1.5f); // one Newton step on the hardware seed
-                const float lij = a[j] * inv;                       // L(i, j) for i >= j
-                const float xj = s[j] * inv;                        // (L^-1)(j, lane)
-                a[j] = lij;
-                s[j] = xj;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c)
-                {
-                        const float lc = bcast(lij, c);
-                        a[c] = fmaf(-lij, lc, a[c]);
-                        s[c] = fmaf(-lc, xj, s[c]);
-                }
-        }
+        factor_diag_column_f32<0>(a, s, ok);
         // one unmasked store per lane and entry: lanes 16-63 hold copies of rows 0-15 and write the same values to the same addresses
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -90,6 +117,7 @@ __device__ __forceinline__ bool factor_diag_tile_f32(double *T, double *Ti, int 
         }
         return ok;
 }
+#undef ASLAM_DPP_FMAC32
 
 /// In: the lower 4x4 tiles of a symmetric positive definite 64x64 matrix in Lt.  Out: its Cholesky factor in Lt (zeros above the
 /// diagonal of the diagonal tiles) and R = (L^-1)^T tiles.  256 threads; starts and ends with a barrier.  Returns false (on wave 0)

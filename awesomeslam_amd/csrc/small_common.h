@@ -366,14 +366,9 @@ __device__ __forceinline__ void chol_panel_share(double *Lt, const double *Dinv,
         }
 }
 
-/// this wave's share of the trailing update after panel kb: S(ib,jb) -= L(ib,kb) L(jb,kb)^T for kb < jb <= ib, without
-/// (kb+1,kb+1), which belongs to the diagonal wave; `widx` in [0, SMALL_WAVES-1) numbers the non-diagonal waves.  (Round 4 also tried leaving the two
-/// helper roles that share the diagonal wave's SIMD idle -- role_of_wave -- so that nothing else issues there: no gain, 112 k -> 115 k cycles.)
-__device__ __forceinline__ void chol_trailing_share(double *Lt, int nt, int kb, int widx, int li, int lg)
+/// one tile of the trailing update after panel kb: S(ib,jb) -= L(ib,kb) L(jb,kb)^T, q = i (i + 1) / 2 + j over the lower triangle kb < jb <= ib
+__device__ __forceinline__ void chol_trailing_tile(double *Lt, int kb, int q, int li, int lg)
 {
-        const int m = nt - kb - 1;
-        const int ntr = m * (m + 1) / 2;
-        for (int q = 1 + widx; q < ntr; q += SMALL_WAVES - 1)
         {
                 int i = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
                 while ((i + 1) * (i + 2) / 2 <= q)
@@ -403,6 +398,25 @@ __device__ __forceinline__ void chol_trailing_share(double *Lt, int nt, int kb, 
                 for (int r = 0; r < 4; ++r)
                         S[(lg + 4 * r) * TLD + li] = t[r];
         }
+}
+
+/// this wave's share of the trailing update after panel kb, without tile (kb+1,kb+1), which belongs to the diagonal wave.  The eleven other waves do not
+/// come to it equally loaded (round 4): a row-block role with a forward-substitution step in this block column has `fwd_load` = nt - kb tile products of
+/// its own first (per-role stamps at n = 131: role 0 busy 48.7 k cycles in the loop, role 7 20.7 k, with the tiles dealt evenly).  So the first
+/// nfree * fwd_load tiles go round the `nfree` waves WITHOUT such a step (`free_slot` in [0, nfree), -1 for the others), the rest round all `nall`
+/// (`all_slot`).  (Round 4 also tried leaving the two helper roles that share the diagonal wave's SIMD idle -- role_of_wave -- so that nothing else
+/// issues there: no gain, 112 k -> 115 k cycles.)
+__device__ __forceinline__ void chol_trailing_share(double *Lt, int nt, int kb, int nfree, int free_slot, int nall, int all_slot, int fwd_load, int li,
+                                                    int lg)
+{
+        const int m = nt - kb - 1;
+        const int T = m * (m + 1) / 2 - 1; // tiles q = 1 .. T
+        const int first = min(T, nfree * fwd_load);
+        if (free_slot >= 0)
+                for (int q = free_slot; q < first; q += nfree)
+                        chol_trailing_tile(Lt, kb, 1 + q, li, lg);
+        for (int q = first + all_slot; q < T; q += nall)
+                chol_trailing_tile(Lt, kb, 1 + q, li, lg);
 }
 
 /// forward substitution step for block column kb on the row block in acc: acc[kb] <- Linv(kb) acc[kb], then
@@ -651,7 +665,7 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
                         __syncthreads();
                         WB(1);
                         forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
-                        chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        chol_trailing_share(Lt, nt, kb, SMALL_WAVES - 2 - nt, -1, SMALL_WAVES - 1, wave, nt - kb, li, lg); // (every row block has a forward step in every block column)
                         WB(0);
                         __syncthreads();
                 }
@@ -697,7 +711,9 @@ __device__ __forceinline__ void cholesky_forward_rows(const double *Src, double 
                         WB(1);
                         if (wave == DW + 1)
                                 forward_vector_block(Lt, Dinv, kb, Y, Tv, lane); // row kb of L and Linv(kb) are final: block kb of Tv = L^-1 Y
-                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        // (role DW + 1 has the vector's block: it takes tiles only with the loaded roles; the free ones are the roles nt .. DW - 1 and DW + 2 ..)
+                        chol_trailing_share(Lt, nt, kb, SMALL_WAVES - 2 - nt, wave == DW + 1 ? -1 : wave - nt - (wave > DW ? 2 : 0), SMALL_WAVES - 1,
+                                            wave < DW ? wave : wave - 1, nt - kb, li, lg);
                         WB(0);
                         __syncthreads();
                 }
@@ -777,7 +793,7 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                         WB(1);
                         if (kb >= rb || rb == nt - 1) // block columns left of the diagonal block of this row block stay zero (the last one carries Y^T: all of them)
                                 forward_step<NT>(acc, Lt, Dinv, nt, kb, li, lg);
-                        chol_trailing_share(Lt, nt, kb, wave, li, lg);
+                        chol_trailing_share(Lt, nt, kb, max(0, nt - 2 - kb) + SMALL_WAVES - 1 - nt, (kb >= rb || rb == nt - 1) ? -1 : rb - kb - 1, SMALL_WAVES - 1, wave, nt - kb, li, lg);
                         WB(0);
                         __syncthreads();
                 }
@@ -856,7 +872,7 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                 {
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
                         __syncthreads();
-                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        chol_trailing_share(Lt, nt, kb, max(0, nt - 2 - kb) + SMALL_WAVES - 1 - nt, max(0, nt - 2 - kb) + wave - nt - (wave > DW ? 1 : 0), SMALL_WAVES - 1, wave < DW ? wave : wave - 1, nt - kb, li, lg);
                         __syncthreads();
                 }
                 __syncthreads(); // [A]
@@ -972,7 +988,7 @@ template <int NT> __device__ __forceinline__ void cholesky_lookahead(double *Lt,
                 {
                         chol_panel_share(Lt, Dinv, nt, kb, wave, li, lg);
                         __syncthreads();
-                        chol_trailing_share(Lt, nt, kb, wave < DW ? wave : wave - 1, li, lg);
+                        chol_trailing_share(Lt, nt, kb, 0, -1, SMALL_WAVES - 1, wave < DW ? wave : wave - 1, 0, li, lg);
                         __syncthreads();
                 }
         }
@@ -1244,7 +1260,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         // equals = first in index order; lane 0 of the group holds landmark 0's starting value and keeps it unless something is
         // strictly smaller -- also when it is an infinity or a NaN), so ties, infinities and NaNs resolve exactly as in the sequential scan.
         // (Round 4: four threads per observation and a pass through LDS before: 8.3 k cycles at n = 131.)
-        constexpr int SCAN_LANES = 8;
+        constexpr int SCAN_LANES = (OBS_CAP > 128) ? 4 : 8; // (the 512-landmark front end has more observations than lanes either way: fewer, longer scans and two exchanges)
         for (int idx = tid; idx < SCAN_LANES * sm.sn; idx += SMALL_WG)
         {
                 const int j = idx / SCAN_LANES, c = idx % SCAN_LANES;
