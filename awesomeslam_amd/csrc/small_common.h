@@ -877,6 +877,9 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                 }
                 __syncthreads(); // [A]
         }
+#ifdef ASLAM_STAMPS
+        unsigned long long tp0_ = __builtin_amdgcn_s_memtime(), tp1_ = 0;
+#endif
         // ---- S^-1 = L^-T L^-1 on ALL twelve waves (round 4: the row-block waves did it alone, row block rb its rb + 1 tiles of (nt - rb) products each --
         // up to 25 tile products on one wave while three waves idled): (S^-1)(rb, jb) = sum_{k >= rb} Linv(k, rb)^T Linv(k, jb), jb <= rb; the 45 lower tiles
         // are dealt in snake order over the waves (costs fall with the tile index: <= 15 products per wave), two products in flight per tile
@@ -926,6 +929,9 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
                         orb[qq] = (tl < ntl) ? rb : -1;
                         ojb[qq] = jb;
                 }
+#ifdef ASLAM_STAMPS
+                tp1_ = __builtin_amdgcn_s_memtime();
+#endif
                 __syncthreads(); // [B] nobody reads L^-1 any more
                 const double r2 = r * r;
 #pragma unroll
@@ -953,6 +959,11 @@ __device__ __forceinline__ void cholesky_inverse_tiles(double *Lt, double *Dinv,
         {
                 wave_busy[2 * wave] += (wave == DW) ? tb_[1] : tb_[0]; // busy inside the factorisation loop (diagonal wave: its WAIT at the barriers instead)
                 wave_busy[2 * wave + 1] += tb_[2]; // diagonal wave: update + factorisation of the next diagonal tile
+                if (wave > DW)
+                {
+                        wave_busy[2 * wave] += tp1_ - tp0_;                               // helper roles: the S^-1 product section ...
+                        wave_busy[2 * wave + 1] += __builtin_amdgcn_s_memtime() - tp1_; // ... and what follows it (barrier [B], r I - r^2 S^-1 to the tiles)
+                }
         }
 #endif
 #undef WB

@@ -21,6 +21,6 @@ def run(L,B,T=264):
     for nm,c in zip(NAMES,cyc): print(f'   {nm:14s} {c:9.0f}  {100*c/cyc.sum():5.1f}%')
     if hasattr(lib,'aslam_debug_wave_busy'):
         w=(ctypes.c_ulonglong*24)(); lib.aslam_debug_wave_busy(core._h,w); w=np.array(list(w),dtype=np.float64).reshape(12,2)/264  # (role index, not physical wave: role 9 = the diagonal wave, its second figure = update + factorisation of the next diagonal tile)
-        print('   per-role cycles/step [row-block roles 0..8: busy in the factorisation loop / behind it; role 9 = the diagonal wave: WAITING at the loop barriers / update + factorisation of the next diagonal tiles]:')
+        print('   per-role cycles/step [row-block roles 0..8: busy in the factorisation loop / behind it; role 9 = the diagonal wave: WAITING at the loop barriers / update + factorisation of the next diagonal tiles; helper roles 10, 11: the S^-1 product section / what follows it]:')
         print('   '+' '.join(f'w{i}:{w[i,0]:.0f}/{w[i,1]:.0f}' for i in range(12)))
 run(64,1)

@@ -12,4 +12,4 @@ core=Core('ekf',tg.dim_cap(L),batch=B,max_obs=tr.max_obs,max_wait=256); core.set
 core.replay(0,64); torch.cuda.synchronize()
 lib=ac.core_lib(); a=(ctypes.c_ulonglong*6)(); lib.aslam_debug_fe_stamps(core._h,a); base=np.array(list(a),float)
 core.replay(64,200); torch.cuda.synchronize(); lib.aslam_debug_fe_stamps(core._h,a); cyc=(np.array(list(a),float)-base)/200
-for nm,c in zip(['intake+copy','toPoint+narrow','scan','combine+Z','wait walk','A'],cyc): print(f'   fe: {nm:16s} {c:9.0f}')
+for nm,c in zip(['intake+copy','toPoint+narrow+A','scan+combine','Z','wait walk','(barrier)'],cyc): print(f'   fe: {nm:16s} {c:9.0f}')
