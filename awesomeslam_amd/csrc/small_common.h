@@ -1293,7 +1293,31 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         k = SCAN_LANES;
                 }
                 constexpr int CH = 8; // candidates fetched together: the LDS reads of a chunk are in flight at once (one at a time: ~ 250 cycles per candidate)
-                for (; k < nl; k += SCAN_LANES * CH)
+                auto candidate = [&](const float2 p, int kk, bool live) {
+                        const float dx = ox - p.x, dy = oy - p.y;
+                        const float d2 = dx * dx + dy * dy;
+                        if (live && d2 < bd2)
+                        {
+                                const float dd = sqrtf(d2);
+                                if (dd < bd)
+                                {
+                                        bd = dd;
+                                        bd2 = d2;
+                                        bk = kk;
+                                }
+                        }
+                };
+                for (; k + (CH - 1) * SCAN_LANES < nl; k += SCAN_LANES * CH) // whole chunks
+                {
+                        float2 p[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                                p[u] = lm[k + u * SCAN_LANES];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                                candidate(p[u], k + u * SCAN_LANES, true);
+                }
+                if (k < nl) // the last, partial one
                 {
                         float2 p[CH];
 #pragma unroll
@@ -1301,21 +1325,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                                 p[u] = lm[min(k + u * SCAN_LANES, nl - 1)];
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
-                        {
-                                const int kk = k + u * SCAN_LANES;
-                                const float dx = ox - p[u].x, dy = oy - p[u].y;
-                                const float d2 = dx * dx + dy * dy;
-                                if (kk < nl && d2 < bd2)
-                                {
-                                        const float dd = sqrtf(d2);
-                                        if (dd < bd)
-                                        {
-                                                bd = dd;
-                                                bd2 = d2;
-                                                bk = kk;
-                                        }
-                                }
-                        }
+                                candidate(p[u], k + u * SCAN_LANES, k + u * SCAN_LANES < nl);
                 }
 #pragma unroll
                 for (int off = 1; off < SCAN_LANES; off <<= 1)
