@@ -354,3 +354,73 @@ def test_batched_step_seam(kind, n, B, dtype, built, monkeypatch):
         worst = max(worst, rel_err(X, Xo), cov_err(P, Po))
         assert rel_err(X, Xo) < tol and cov_err(P, Po) < tol and core.status(b) == 0, b
     print(f"batched step {kind} n={n} B={B} {dtype}: worst rel err X/P over the batch {worst:.2e}")
+
+
+@pytest.mark.parametrize("kind", ["ekf", "ukf"])
+def test_association_ties_collisions_and_non_finite_readings(kind, built):
+    """The association's corner cases, bit-exact against the oracle (ekf.cpp:159-181, 217-253 / ukf.cpp:129-150): two mapped landmarks at the SAME
+    place (the first in index order wins, also when neither is landmark 0), two readings of one landmark in one message (the last wins), readings with
+    an infinite range, a NaN range and a NaN bearing (never associated, never matched on the wait-list: one more entry per callback each), and two new
+    readings close to each other (the second matches the first's wait-list entry; promotion after MIN_LANDMARK_OCC sightings grows the state).
+    The device scans with several lanes per reading and combines partial results; the reference walks the lists in order."""
+    import torch
+    from awesomeslam_amd.core import Core
+    from oracle.c_oracle import CFilter
+
+    lm = np.array([[12.0, 0.0], [12.0, 0.0], [13.0, -2.0], [14.0, 3.0], [14.0, 3.0], [15.0, 1.0]])
+    n = 3 + 2 * len(lm)
+    X = np.concatenate([[0.0, 0.0, 0.0], lm.ravel()])
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(n, n)) * 0.01
+    P = A @ A.T + np.diag([1e-3] * 3 + [2e-2] * (n - 3))
+    rb = lambda p: (np.float32(np.hypot(*p)), np.float32(np.arctan2(p[1], p[0])))
+    Z = X.copy()
+    for i, p in enumerate(lm):
+        Z[3 + 2 * i], Z[4 + 2 * i] = rb(p)
+        Z[3 + 2 * i] += np.float32(0.01)                # (the stored readings differ from the new ones: an association is visible in Z)
+    T, max_obs = 12, 16
+    nan, inf = np.float32("nan"), np.float32("inf")
+    msg = [rb(lm[0]),                                   # on landmarks 0 and 1 (identical until the first update): index 0 wins
+           rb(lm[2] + [0.02, -0.01]),
+           rb(lm[3]),                                   # on landmarks 3 and 4: index 3 wins
+           rb(lm[5] + [0.05, 0.0]), rb(lm[5] + [-0.03, 0.02]),  # landmark 5 twice: the last one wins
+           (inf, np.float32(0.1)), (nan, np.float32(0.2)), (np.float32(5.0), nan),
+           (np.float32(8.0), np.float32(0.5)), (np.float32(8.05), np.float32(0.5))]  # a new landmark: 2 sightings per callback
+    obs = np.zeros((1, T, max_obs, 2), np.float32)
+    obs[0, :, :len(msg)] = np.array(msg, np.float32)
+    obs[0, 1::2, 3], obs[0, 1::2, 4] = obs[0, 1::2, 4].copy(), obs[0, 1::2, 3].copy()  # swap the two readings of landmark 5 every other callback
+    odom = np.zeros((1, T, 8))
+    odom[0, :, 2] = 1.0                                 # qw: the robot stands still at the origin
+    tr = tg.Trace(odom, np.full((1, T), 0.25, np.float32), np.ones((1, T), np.uint8), np.full((1, T), len(msg), np.int32), obs,
+                  lm[None], np.zeros((1, T, 3)))
+    core = Core(kind, 30, batch=1, max_obs=max_obs, max_wait=512)
+    o = CFilter(kind, 30)
+    core.set_state(0, n, X, Z, P)
+    o.set_state(n, X, Z, P)
+    core.set_trace(tr)
+    p = torch.zeros((1, T, 3), dtype=torch.float64, device="cuda")
+    d = torch.zeros((1, T), dtype=torch.int32, device="cuda")
+    probe = Core(kind, 30, batch=1, max_obs=max_obs, max_wait=512)  # first callback alone: the ties went to the lower index
+    probe.set_state(0, n, X, Z, P)
+    probe.set_trace(tr)
+    probe.replay(0, 1, p.data_ptr(), d.data_ptr())
+    torch.cuda.synchronize()
+    Z1 = probe.state(0)[1]
+    assert Z1[3] == np.float32(12.0) and Z1[5] == Z[5] and Z1[9] == rb(lm[3])[0] and Z1[11] == Z[11], Z1
+    core.replay(0, T, p.data_ptr(), d.data_ptr())
+    torch.cuda.synchronize()
+    po, do = o.replay(tr[0])
+    dims = d.cpu().numpy()[0]
+    assert np.array_equal(dims, do) and dims[0] == n and dims[-1] == n + 2, dims  # grown by the promoted landmark
+    assert core.status(0) == 0
+    Xg, Zg, Pg = core.state(0)
+    Xo, Zo, Po = o.state()
+    assert np.array_equal(Zg, Zo), "Z (association result) must be bit-exact"
+    assert np.all(np.isfinite(Zg)) and np.all(np.isfinite(Xg))
+    w, wo = core.wait_list(0), o.wait_list()
+    assert len(w[0]) == len(wo[0]) == 1 + 3 * T
+    for a, c in zip(w, wo):
+        assert np.array_equal(a, c, equal_nan=True), "wait-list must be bit-exact (NaN entries alike)"
+    errs = rel_err(p.cpu().numpy()[0], po), rel_err(Xg, Xo), cov_err(Pg, Po)
+    print("association corner cases (%s): rel err pose/X/P = %.2e %.2e %.2e; wait-list %d entries" % ((kind,) + errs + (len(w[0]),)))
+    assert max(errs) < REL_TOL, errs
