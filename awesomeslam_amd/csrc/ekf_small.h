@@ -197,19 +197,31 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 const int n = sm.n;
                 const int nl = (n - 3) / 2;
                 const int nt = (n + 15) >> 4;
-                if (tid == 0)
+                double xp0, xp1, xp2; // the predicted pose
+                if (MODE == MODE_REPLAY)
                 {
-                        double p0 = sX[0], p1 = sX[1], p2 = sX[2];
-                        stateTransition(p0, p1, p2, sm.vx, sm.az, sm.dt, false, 0.0);
-                        sX[0] = p0;
-                        sX[1] = p1;
-                        sX[2] = (double)normalizeAngle((float)p2);
+                        // formed by an idle wave of the front end (small_frontend): nobody reads sX[0..2] before the barrier behind the H coefficients
+                        xp0 = sm.pp0, xp1 = sm.pp1, xp2 = sm.pp2;
+                        if (tid == 0)
+                                sX[0] = xp0, sX[1] = xp1, sX[2] = xp2;
                 }
-                __syncthreads();
+                else
+                {
+                        if (tid == 0)
+                        {
+                                double p0 = sX[0], p1 = sX[1], p2 = sX[2];
+                                stateTransition(p0, p1, p2, sm.vx, sm.az, sm.dt, false, 0.0);
+                                sX[0] = p0;
+                                sX[1] = p1;
+                                sX[2] = (double)normalizeAngle((float)p2);
+                        }
+                        __syncthreads();
+                        xp0 = sX[0], xp1 = sX[1], xp2 = sX[2];
+                }
                 // updateH (ekf.cpp:117-134) as per-landmark coefficients, their 2x2 inverse, and Y = Z - h(X)
                 for (int i = tid; i < nl; i += SMALL_WG)
                 {
-                        const double x0 = sX[0], x1 = sX[1];
+                        const double x0 = xp0, x1 = xp1;
                         const double lx = sX[3 + 2 * i], ly = sX[4 + 2 * i];
                         const double ddx = lx - x0, ddy = ly - x1;
                         const float hyp = (float)(ddx * ddx + ddy * ddy);
@@ -230,15 +242,15 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                         hc[7 * NLM] = h00 / det;
                         // measurementFunction, common.h:78-90
                         const double hr = sqrt(ddx * ddx + ddy * ddy);
-                        const double hb = atan2(ddy, ddx) - sX[2];
+                        const double hb = atan2(ddy, ddx) - xp2;
                         sY[3 + 2 * i] = sZ[3 + 2 * i] - hr;
                         sY[4 + 2 * i] = (double)normalizeAngle((float)(sZ[4 + 2 * i] - hb));
                 }
                 if (tid == 0)
                 {
-                        sY[0] = sZ[0] - sX[0];
-                        sY[1] = sZ[1] - sX[1];
-                        sY[2] = (double)normalizeAngle((float)(sZ[2] - sX[2]));
+                        sY[0] = sZ[0] - xp0;
+                        sY[1] = sZ[1] - xp1;
+                        sY[2] = (double)normalizeAngle((float)(sZ[2] - xp2));
                 }
                 for (int i = n + tid; i < NP; i += SMALL_WG)
                         sY[i] = 0.0;

@@ -120,6 +120,7 @@ struct SmallShared
         uint32_t status;
         float vx, az, dt, yaw;
         double px, py, tvx, twz, a00, a10;
+        double pp0, pp1, pp2; // the predicted pose of this callback (EKF replay: formed by an idle wave of the front end)
 };
 
 template <int NT> struct SmallLayout
@@ -1260,6 +1261,41 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         sm.az = (float)sm.twz;
                 }
         }
+        // The predicted pose (stateTransitionFunction, common.h:46-75, ekf.cpp:296) depends on the odom message and on the pose the last callback left
+        // (param.X = param.Z on the first one, ekf.cpp:87-91): a lane of a third idle wave forms it here instead of thread 0 alone in front of the H
+        // coefficients (round 4: ~ 1.5 k cycles and a barrier per callback of the single-CU EKF).
+        if (IS_EKF && tid >= SMALL_WG - 192 && tid < SMALL_WG - 128)
+        {
+                // stateTransition (device_common.h) with its two angles on two lanes: the same calls on the same arguments, side by side
+                const int l = tid & 63;
+                const bool ix = (sm.flags & FLAG_INIT_X) != 0;
+                double p0 = ix ? sZ[0] : sX[0], p1 = ix ? sZ[1] : sX[1], p2 = ix ? sZ[2] : sX[2];
+                const float vx = (float)sm.tvx, az = (float)sm.twz, dt = sm.dt;
+                const bool arc = fabsf(az) > 0.001;
+                const double th = p2, th2 = th + (double)(az * dt);
+                const double ang = ((l & 1) && arc) ? th2 : th;
+                const double sn = sin(ang), cs = cos(ang);
+                const double sn2 = __shfl_down(sn, 1), cs2 = __shfl_down(cs, 1);
+                if (l == 0)
+                {
+                        if (arc)
+                        {
+                                const float r = vx / az;
+                                p0 += (double)r * (-sn + sn2);
+                                p1 += (double)r * (cs - cs2);
+                        }
+                        else
+                        {
+                                const float vdt = vx * dt;
+                                p0 += (double)vdt * cs;
+                                p1 += (double)vdt * sn;
+                        }
+                        p2 += (double)(az * dt);
+                        sm.pp0 = p0;
+                        sm.pp1 = p1;
+                        sm.pp2 = (double)normalizeAngle((float)p2);
+                }
+        }
         __syncthreads();
         FE_STAMP(6); // toPoint + landmark narrowing + A
         // nearest mapped landmark of every observation (ekf.cpp:159-173).  Eight lanes per observation scan the landmarks
@@ -1282,7 +1318,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 // eulerDistance, tools.h:53-59.  The reference subtracts in double and narrows; for two binary32 inputs that is the
                 // binary32 difference bit for bit (the double difference is exact unless the exponents are more than 28 apart, and
                 // then both round to the larger operand), without six slow f64 instructions
-                int k = c;
+                int k = c; // (every lane of a group takes the same number of chunks: landmark 0, lane 0's starting value, is skipped by the predicate below)
                 if (c == 0 && nl > 0) // mindist starts as the distance to landmark 0, whatever it is
                 {
                         const float2 p = lm[0];
@@ -1290,7 +1326,6 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         bd2 = dx * dx + dy * dy;
                         bd = sqrtf(bd2);
                         bk = 0;
-                        k = SCAN_LANES;
                 }
                 constexpr int CH = 8; // candidates fetched together: the LDS reads of a chunk are in flight at once (one at a time: ~ 250 cycles per candidate)
                 auto candidate = [&](const float2 p, int kk, bool live) {
@@ -1315,7 +1350,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                                 p[u] = lm[k + u * SCAN_LANES];
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
-                                candidate(p[u], k + u * SCAN_LANES, true);
+                                candidate(p[u], k + u * SCAN_LANES, k + u * SCAN_LANES > 0);
                 }
                 if (k < nl) // the last, partial one
                 {
@@ -1325,7 +1360,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                                 p[u] = lm[min(k + u * SCAN_LANES, nl - 1)];
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
-                                candidate(p[u], k + u * SCAN_LANES, k + u * SCAN_LANES < nl);
+                                candidate(p[u], k + u * SCAN_LANES, k + u * SCAN_LANES < nl && k + u * SCAN_LANES > 0);
                 }
 #pragma unroll
                 for (int off = 1; off < SCAN_LANES; off <<= 1)
