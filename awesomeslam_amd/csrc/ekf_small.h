@@ -197,6 +197,8 @@ __global__ __launch_bounds__(SMALL_WG) void ekf_small_kernel(DevView d, int64_t 
                 const int n = sm.n;
                 const int nl = (n - 3) / 2;
                 const int nt = (n + 15) >> 4;
+                if (MODE == MODE_REPLAY && s + 1 < nsteps && __builtin_amdgcn_readfirstlane(tid_launch) >= SMALL_WG - 64) // (a scalar branch: one whole wave)
+                        small_prefetch_intake<SMALL_OBS_CAP>(d, L, b, t + 1, tid_launch & 63); // (the last wave has no landmark of the loop below at n <= 143)
                 double xp0, xp1, xp2; // the predicted pose
                 if (MODE == MODE_REPLAY)
                 {

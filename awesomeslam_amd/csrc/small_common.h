@@ -121,6 +121,11 @@ struct SmallShared
         float vx, az, dt, yaw;
         double px, py, tvx, twz, a00, a10;
         double pp0, pp1, pp2; // the predicted pose of this callback (EKF replay: formed by an idle wave of the front end)
+        // the NEXT callback's messages, fetched while this one computes (small_prefetch_intake): valid for callback staged_t
+        long long staged_t;
+        double nx_px, nx_py, nx_tvx, nx_twz;
+        float nx_yaw, nx_dt;
+        int nx_new, nx_nobs;
 };
 
 template <int NT> struct SmallLayout
@@ -1069,6 +1074,7 @@ template <int MODE> __device__ __forceinline__ void small_load(const DevView &d,
         if (tid == 0)
         {
                 sm.n = d.n[b];
+                sm.staged_t = -1;
                 sm.flags = d.flags[b];
                 sm.status = d.status[b];
                 sm.sn = d.sens_n[b];
@@ -1133,6 +1139,40 @@ template <int MODE> __device__ __forceinline__ void small_store(const DevView &d
         }
 }
 
+/// The messages of callback t1 (= the next one of this launch) into LDS, by ONE wave with nothing else to do at the call site, while the others compute:
+/// the front end of t1 then starts from LDS instead of two dependent global round trips (~ 2 k cycles per callback; round 4).  The staging area is the
+/// association's partial-result scratch, unused since the scan combines in registers (entries 0 .. 15 stay the wait-list walk's).  Call between two
+/// barriers of the callback, outside the front end; `lane` = 0 .. 63.
+template <int OBS_CAP> __device__ __forceinline__ void small_prefetch_intake(const DevView &d, const SmallLds &L, int b, int64_t t1, int lane)
+{
+        SmallShared &sm = *L.sm;
+        const int ocap = min(d.max_obs, OBS_CAP); // (OBS_CAP <= 4 OBS_CAP - 16: the staging area holds a whole message)
+        float *const stg_r = L.sPd + 16, *const stg_b = reinterpret_cast<float *>(L.sPi) + 16;
+        const float *src = d.tr_obs + ((size_t)b * d.T + t1) * d.max_obs * 2;
+        for (int j0 = 0; j0 < ocap; j0 += 128)
+        {
+                const int ja = j0 + lane, jb = j0 + 64 + lane;
+                float ra = 0.f, ba = 0.f, rb2 = 0.f, bb2 = 0.f;
+                if (ja < ocap)
+                        ra = src[2 * ja], ba = src[2 * ja + 1];
+                if (jb < ocap)
+                        rb2 = src[2 * jb], bb2 = src[2 * jb + 1];
+                if (ja < ocap)
+                        stg_r[ja] = ra, stg_b[ja] = ba;
+                if (jb < ocap)
+                        stg_r[jb] = rb2, stg_b[jb] = bb2;
+        }
+        if (lane == 0)
+        {
+                const size_t o = (size_t)b * d.T + t1;
+                const double px = d.tr_pose[2 * o], py = d.tr_pose[2 * o + 1], tvx = d.tr_twist[2 * o], twz = d.tr_twist[2 * o + 1];
+                const float yaw = d.tr_yaw[o], dt = d.tr_dt[o];
+                const int nw = d.tr_new[o], k = d.tr_nobs[o];
+                sm.nx_px = px, sm.nx_py = py, sm.nx_tvx = tvx, sm.nx_twz = twz, sm.nx_yaw = yaw, sm.nx_dt = dt, sm.nx_new = nw, sm.nx_nobs = k;
+                sm.staged_t = t1;
+        }
+}
+
 /// One callback's host-side work on the device: cbSensorLandmark (ekf.cpp:102-114 / ukf.cpp:98-110) when a
 /// sensor message precedes this odom message, then updateZandA (ekf.cpp:137-213) / updateZ (ukf.cpp:113-180):
 /// association, wait-list (ekf.cpp:217-253), promotion and growth (ekf.cpp:255-290), A (EKF), init_x.
@@ -1152,11 +1192,14 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         unsigned long long fe_last = __builtin_amdgcn_s_memtime();
 #endif
         // ================= message intake
-        // The observation row of this callback is fetched next to thread 0's scalars (one global latency instead of two; the row has max_obs entries
-        // whatever tr_nobs says, and it is only kept when the message is new).
+        const int ocap = min(d.max_obs, OBS_CAP);
+        float *const stg_r = L.sPd + 16, *const stg_b = reinterpret_cast<float *>(L.sPi) + 16; // (the scratch of the wait-list walk is entries 0 .. 11)
+        const bool staged = (sm.staged_t == t); // published by the barriers of the previous callback; uniform
+        // Not staged (the first callback of a launch, the large-state front end): the observation row of this callback is fetched next to thread 0's
+        // scalars (one global latency instead of two; the row has max_obs entries whatever tr_nobs says, and it is only kept when the message is new).
         const float *src = d.tr_obs + ((size_t)b * d.T + t) * d.max_obs * 2;
         float ob0r = 0.0f, ob0b = 0.0f;
-        if (tid < min(d.max_obs, OBS_CAP))
+        if (!staged && tid < ocap)
         {
                 ob0r = src[2 * tid];
                 ob0b = src[2 * tid + 1];
@@ -1164,18 +1207,28 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         if (tid == 0)
         {
                 const size_t o = (size_t)b * d.T + t;
-                sm.px = d.tr_pose[2 * o];
-                sm.py = d.tr_pose[2 * o + 1];
-                sm.yaw = d.tr_yaw[o];
-                sm.tvx = d.tr_twist[2 * o];
-                sm.twz = d.tr_twist[2 * o + 1];
-                sm.dt = d.tr_dt[o];
-                sm.obs_new = d.tr_new[o];
-                int k = d.tr_nobs[o];
+                int k;
+                if (staged)
+                {
+                        sm.px = sm.nx_px, sm.py = sm.nx_py, sm.yaw = sm.nx_yaw, sm.tvx = sm.nx_tvx, sm.twz = sm.nx_twz, sm.dt = sm.nx_dt;
+                        sm.obs_new = sm.nx_new;
+                        k = sm.nx_nobs;
+                }
+                else
+                {
+                        sm.px = d.tr_pose[2 * o];
+                        sm.py = d.tr_pose[2 * o + 1];
+                        sm.yaw = d.tr_yaw[o];
+                        sm.tvx = d.tr_twist[2 * o];
+                        sm.twz = d.tr_twist[2 * o + 1];
+                        sm.dt = d.tr_dt[o];
+                        sm.obs_new = d.tr_new[o];
+                        k = d.tr_nobs[o];
+                }
                 if (k > d.max_obs || k > OBS_CAP)
                 {
                         sm.status |= 8u; // ASLAM_ST_OBS_OVERFLOW
-                        k = min(d.max_obs, OBS_CAP);
+                        k = ocap;
                 }
                 sm.nobs = k;
                 sm.any_miss = 0;
@@ -1186,15 +1239,26 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         if (sm.obs_new)
         {
                 // cbSensorLandmark, ekf.cpp:102-114
-                if (tid < sm.nobs)
+                if (staged)
                 {
-                        sSr[tid] = ob0r;
-                        sSb[tid] = ob0b;
+                        for (int j = tid; j < sm.nobs; j += SMALL_WG)
+                        {
+                                sSr[j] = stg_r[j];
+                                sSb[j] = stg_b[j];
+                        }
                 }
-                for (int j = tid + SMALL_WG; j < sm.nobs; j += SMALL_WG)
+                else
                 {
-                        sSr[j] = src[2 * j];
-                        sSb[j] = src[2 * j + 1];
+                        if (tid < sm.nobs)
+                        {
+                                sSr[tid] = ob0r;
+                                sSb[tid] = ob0b;
+                        }
+                        for (int j = tid + SMALL_WG; j < sm.nobs; j += SMALL_WG)
+                        {
+                                sSr[j] = src[2 * j];
+                                sSb[j] = src[2 * j + 1];
+                        }
                 }
                 if (tid == 0)
                 {
@@ -1241,10 +1305,12 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         // Update A, ekf.cpp:206-212 (the UKF node has no A), and slam()'s binary32 arguments: they depend on the odom message alone, so the last two waves
         // form them here -- one the cosines, one the sines, the two angles on two lanes side by side -- instead of thread 0 one libm call after the other
         // behind the wait-list walk (round 4: ~ 3 k cycles of a callback's 150 k at n = 131)
-        if (tid >= SMALL_WG - 128)
+        // (whole waves: scalar branches on the wave index -- no EXEC-masked region around the libm calls for the register allocator to spill into)
+        const int fe_wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+        if (fe_wave >= SMALL_WG / 64 - 2)
         {
                 const int l = tid & 63;
-                const bool sines = tid < SMALL_WG - 64; // (wave-uniform)
+                const bool sines = fe_wave == SMALL_WG / 64 - 2; // (wave-uniform)
                 if (IS_EKF && sm.tvx != 0.0 && sm.twz != 0.0)
                 {
                         const float delta_theta = (float)(sm.twz * (double)sm.dt);
@@ -1264,7 +1330,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         // The predicted pose (stateTransitionFunction, common.h:46-75, ekf.cpp:296) depends on the odom message and on the pose the last callback left
         // (param.X = param.Z on the first one, ekf.cpp:87-91): a lane of a third idle wave forms it here instead of thread 0 alone in front of the H
         // coefficients (round 4: ~ 1.5 k cycles and a barrier per callback of the single-CU EKF).
-        if (IS_EKF && tid >= SMALL_WG - 192 && tid < SMALL_WG - 128)
+        if (IS_EKF && fe_wave == SMALL_WG / 64 - 3)
         {
                 // stateTransition (device_common.h) with its two angles on two lanes: the same calls on the same arguments, side by side
                 const int l = tid & 63;
@@ -1410,8 +1476,10 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                         sWx[i] = a;
                         sWy[i] = c;
                 }
+                __syncthreads();
         }
-        __syncthreads();
+        // (without a miss -- the steady state of a mapped world -- nothing below reads what the loops above wrote before the barrier that ends the
+        // front end: the two barriers of the wait-list walk are taken only with it; any_miss was published by the barrier behind the scan)
         if (sm.any_miss)
         {
                 // Unassociated observations go through the wait-list in message order (they touch nothing the associated ones touch); counts only
@@ -1559,8 +1627,9 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
                 }
         }
         FE_STAMP(9); // wait-list walk
-        __syncthreads();
-        FE_STAMP(10); // A
+        if (sm.any_miss)
+                __syncthreads(); // (grew, n, the new entries of X / Z: thread 0's)
+        FE_STAMP(10);
         if (sm.grew)
         {
                 // conservativeResizeLike(Identity * UKF_KP_LANDMARK_POSE), ekf.cpp:277
@@ -1581,6 +1650,7 @@ __device__ __forceinline__ bool small_frontend(const DevView &d, const SmallLds 
         if (sm.flags & FLAG_INIT_X)
         {
                 // param.X = param.Z once, ekf.cpp:87-91
+                __syncthreads(); // (Z is complete: the loops above may have run without a barrier behind them)
                 for (int i = tid; i < sm.n; i += SMALL_WG)
                         sX[i] = sZ[i];
                 __syncthreads();

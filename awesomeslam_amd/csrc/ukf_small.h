@@ -445,6 +445,8 @@ __global__ __launch_bounds__(SMALL_WG) void ukf_small_kernel(DevView d, UkfView 
                         }
                 }
                 __syncthreads();
+                if (MODE == MODE_REPLAY && s + 1 < nsteps && __builtin_amdgcn_readfirstlane(tid_launch) >= SMALL_WG - 64) // (a scalar branch: one whole wave)
+                        small_prefetch_intake<SMALL_OBS_CAP>(d, L, b, t + 1, tid_launch & 63); // (a helper role of the factorisation: the diagonal wave's first tile covers the wait)
                 cholesky_lookahead<NT>(Lt, Dinv, nt, tid, &sm.status);
 
                 ASLAM_STAMP(1);

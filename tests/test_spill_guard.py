@@ -143,3 +143,20 @@ def test_vmcnt_protocol_detector(tmp_path):
         p.write_text(STRIP % ("\tv_add_f32_e32 v1, v2, v3", extra))
         f, _ = g.scan(str(p))
         assert f and any(frag in x[2] for x in f), (name, f)
+
+
+def test_dpp_hazard_detector(tmp_path):
+    """A DPP instruction must not read a VGPR that a VALU instruction wrote less than two wait states earlier (gfx90a+): the DPP fmacs of the
+    diagonal-tile factorisations are inline assembly, which hipcc's hazard recogniser does not look into (round 4)."""
+    import check_dpp_hazard as g
+
+    dpp = "\tv_fmac_f64_dpp v[8:9], -v[92:93], v[92:93] row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+    ok = tmp_path / "ok.s"
+    ok.write_text("k:\n\tv_mul_f64 v[92:93], v[14:15], s[70:71]\n\ts_nop 1\n" + dpp + dpp + "\tv_mov_b32_e32 v7, v1\n\tv_add_f32_e32 v2, v3, v4\n" + dpp)
+    assert g.check(str(ok)) == []
+    for name, body in (("one_wait_state.s", "k:\n\tv_mul_f64 v[92:93], v[14:15], s[70:71]\n\ts_nop 0\n" + dpp),
+                       ("copy_in_front.s", "k:\n\tv_mul_f64 v[92:93], v[14:15], s[70:71]\n\ts_nop 1\n" + dpp + "\tv_mov_b32_e32 v93, v1\n" + dpp),
+                       ("half_of_the_pair.s", "k:\n\tv_mov_b32_e32 v92, v1\n\tv_add_f32_e32 v2, v3, v4\n" + dpp)):
+        p = tmp_path / name
+        p.write_text(body)
+        assert len(g.check(str(p))) == 1, name

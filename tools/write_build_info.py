@@ -46,7 +46,7 @@ def main():
         "hipcc": ver,
         "arch": "gfx950",
         "ukf": ukf,
-        "guards": ("check_spill_exec + check_agpr_strip + check_vmcnt_protocol clean on the assembly of this compilation" if guards
+        "guards": ("check_spill_exec + check_agpr_strip + check_vmcnt_protocol + check_dpp_hazard clean on the assembly of this compilation" if guards
                    else "NOT RUN (GUARDS=0): diagnostic library, never loaded by awesomeslam_amd.core"),
     }
     out = os.path.join(os.path.dirname(os.path.abspath(lib)), "build_info.json" if guards else "build_info_unguarded.json")
