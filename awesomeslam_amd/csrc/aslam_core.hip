@@ -71,7 +71,8 @@ struct aslam_ctx
         // launches of one group (one-wave diagonal factorisations, the front end, short-K panels) then overlap the GEMMs of
         // the others
         static constexpr int LARGE_GROUPS = 8; // capacity; the default below was chosen by measurement (profiles/)
-        int large_groups = 4;                  // ASLAM_LARGE_GROUPS=1..8 overrides (1 = a single stream, for per-kernel profiling)
+        int large_groups = 3;                  // ASLAM_LARGE_GROUPS=1..8 overrides (1 = a single stream, for per-kernel profiling); 3: 88 / 88 / 80 of 256 filters --
+                                               // measured best at the end of round 4 (tools/manual/sweep_groups.sh: 37.4 - 38.0 k filter-steps/s against 36.6 - 36.8 k with 4, 36.5 - 37.1 k with 2)
         // binary32 mode: Cholesky of S as ONE launch with a filter per workgroup (large_chol_resident) when the batch can fill the
         // chip that way, as 33 multi-workgroup launches (diagonal block + panel per block column) for few filters.
         // ASLAM_CHOL_RESIDENT=0/1 forces one form.
@@ -413,7 +414,7 @@ int launch_large_T(aslam_ctx *c, LargeView<T> &lv, int grid, int64_t t0, int nst
                 for (int s = 0; s < nsteps; ++s)
                         chain(g, s);
         }
-        else if (Bz < 8 * NG)
+        else if (Bz < std::max(32, 8 * NG)) // (one group below 32 filters, as with the former default of four groups)
         {
                 Group g = make_group(0, Bz, st);
                 for (int s = 0; s < nsteps; ++s)

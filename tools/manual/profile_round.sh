@@ -46,26 +46,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 python3 tools/pmc_summary.py $OUT/sq > $OUT/pmc_sq_summary.txt 2>&1
 rm -rf $OUT/sq
 unset ASLAM_LARGE_GROUPS
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o p -- python3 bench.py --no-sub --no-legs --cpu-sample 0 --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$C.err
-  python3 - $OUT $C <<"PY"
-import csv, glob, sys, collections
-out, c = sys.argv[1], sys.argv[2]
-f = glob.glob(out + "/pmc_" + c + "/**/*counter_collection.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "large_" in r["Kernel_Name"] and "<double" not in r["Kernel_Name"] and int(r["Grid_Size"]) >= 64 * 256]
-rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-last = rows[-480:]  # one bench step = 20 callbacks x 6 launches x 4 stream groups
-by = collections.Counter()
-for r in last:
-    by[r["Kernel_Name"].split("(")[0].replace("void aslam::", "")[:40]] += float(r["Counter_Value"])
-with open(out + "/pmc_" + c + ".txt", "w") as o:
-    print("%s KB over the %d dispatches of the last bench step (20 callbacks x 256 filters): %.1f" % (c, len(last), sum(by.values())), file=o)
-    for k, v in by.most_common():
-        print("   %-42s %14.1f KB = %6.2f MB per filter and callback" % (k, v, v / 1024 / 5120), file=o)
-print(open(out + "/pmc_" + c + ".txt").read())
-PY
-  rm -rf $OUT/pmc_$C
-done
+bash tools/manual/profile_traffic.sh $TAG
 cp $OUT/stats4/*/*kernel_stats.csv $OUT/kernel_stats_4groups.csv 2>/dev/null || find $OUT/stats4 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_4groups.csv \;
 rm -rf $OUT/stats4
 echo profile_round done
